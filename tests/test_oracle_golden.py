@@ -1,0 +1,279 @@
+"""Pins oracle/ (our CPU restatement) against the golden vectors recorded from the reference itself
+(oracle/make_golden.py).  CPU only."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dpi_oracle as O
+from conftest import jstr
+
+torch.set_num_threads(4)
+
+
+def T(a, grad=False):
+    t = torch.from_numpy(np.array(a, dtype=np.float32))
+    return t.requires_grad_(True) if grad else t
+
+
+def close(a, b, rtol=1e-5, atol=1e-6, what=""):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+def relnorm(a, b):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    return float(np.linalg.norm(a.ravel() - b.ravel()) / (np.linalg.norm(b.ravel()) + 1e-30))
+
+
+# ---------------------------------------------------------------------------------------------
+CONVS = ["conv3d_k3s1", "conv3d_k3s1_wide", "conv3d_k3s2_odd", "conv3d_k3s2_even", "conv3d_k1",
+         "conv2d_k3s1", "conv2d_k3s2", "conv2d_k1"]
+
+
+@pytest.mark.parametrize("name", CONVS)
+def test_conv(golden, name):
+    g = golden("ops")[name]
+    stride = 2 if "s2" in name else 1
+    x, w, b = T(g["x"], True), T(g["state"]["0.weight"], True), T(g["state"]["0.bias"], True)
+    y = O.conv_nd(x, w, b, stride)
+    close(y, g["y"], 1e-5, 1e-5, "y")
+    y.backward(T(g["dy"]))
+    close(x.grad, g["dx"], 1e-5, 1e-5, "dx")
+    close(w.grad, g["grads"]["0.weight"], 1e-5, 2e-5, "dw")
+    close(b.grad, g["grads"]["0.bias"], 1e-5, 2e-5, "db")
+
+
+@pytest.mark.parametrize("name", ["bn3d", "bn2d"])
+def test_bn(golden, name):
+    g = golden("ops")[name]
+    st = g["state"]
+    x, ga, be = T(g["x"], True), T(st["weight"], True), T(st["bias"], True)
+    rm, rv = T(st["running_mean"]), T(st["running_var"])
+    nbt = torch.tensor(int(st["num_batches_tracked"]))
+    y = O.batch_norm_train(x, ga, be, rm, rv, nbt)
+    close(y, g["y"], 1e-5, 1e-5)
+    y.backward(T(g["dy"]))
+    close(x.grad, g["dx"], 1e-4, 1e-5)
+    close(ga.grad, g["grads"]["weight"], 1e-5, 1e-5)
+    close(be.grad, g["grads"]["bias"], 1e-5, 1e-5)
+    close(rm, g["state_after"]["running_mean"], 1e-6, 1e-7)
+    close(rv, g["state_after"]["running_var"], 1e-6, 1e-7)
+    assert int(nbt) == int(g["state_after"]["num_batches_tracked"])
+
+
+def test_lrelu(golden):
+    g = golden("ops")["lrelu"]
+    x = T(g["x"], True)
+    y = O.activation("LeakyReLU", x)
+    close(y, g["y"], 0, 0)
+    y.backward(T(g["dy"]))
+    close(x.grad, g["dx"], 0, 0)
+
+
+@pytest.mark.parametrize("name,mode", [("up3d_nearest", "nearest"), ("up3d_trilinear", "trilinear"),
+                                       ("up3d_trilinear_1", "trilinear"), ("up2d_nearest", "nearest"),
+                                       ("up2d_bilinear", "bilinear")])
+def test_upsample(golden, name, mode):
+    g = golden("ops")[name]
+    x = T(g["x"], True)
+    y = O.upsample2x(x, mode)
+    close(y, g["y"], 1e-6, 1e-6)
+    y.backward(T(g["dy"]))
+    close(x.grad, g["dx"], 1e-5, 1e-6)
+
+
+def test_concat_crop(golden):
+    for name in ("concat3d_crop", "concat2d_crop"):
+        g = golden("ops")[name]
+        x = T(g["x"], True)
+        deep = O.upsample2x(O.conv_nd(x, T(g["state"]["1.0.0.weight"]), T(g["state"]["1.0.0.bias"]), 2), "nearest")
+        y = O.concat_crop([x, deep])
+        close(y, g["y"], 1e-5, 1e-5)
+        y.backward(T(g["dy"]))
+        close(x.grad, g["dx"], 1e-5, 1e-5)
+
+
+def _prefixed(state, pre):
+    return {pre + "." + k: v for k, v in state.items()}
+
+
+@pytest.mark.parametrize("name", ["conv3dbn", "conv2dbn"])
+def test_convbn(golden, name):
+    g = golden("ops")[name]
+    S = O.NetState(_prefixed(g["state"], "b"))
+    x = T(g["x"], True)
+    y = (O._cba3 if name == "conv3dbn" else O._cba2)(S, "b", x, "LeakyReLU")
+    close(y, g["y"], 1e-5, 1e-5)
+    y.backward(T(g["dy"]))
+    close(x.grad, g["dx"], 1e-4, 1e-5)
+    for k, v in g["grads"].items():
+        # conv bias feeding a BN has an analytically-zero gradient
+        atol = 2e-5 if not k.endswith("0.bias") else 1e-4
+        close(S.P["b." + k].grad, v, 1e-4, atol, k)
+
+
+@pytest.mark.parametrize("name", ["block3d", "block3d_u16", "respath3d", "block2d", "respath2d"])
+def test_blocks(golden, name):
+    g = golden("blocks")[name]
+    S = O.NetState(_prefixed(g["state"], "b"))
+    fn = {"block3d": O.block3d, "block3d_u16": O.block3d, "respath3d": O.respath3d,
+          "block2d": O.block2d, "respath2d": O.respath2d}[name]
+    x = T(g["x"], True)
+    y = fn(S, "b", x, "LeakyReLU")
+    close(y, g["y"], 1e-4, 1e-5)
+    y.backward(T(g["dy"]))
+    assert relnorm(x.grad, g["dx"]) < 1e-4
+    for k, v in g["grads"].items():
+        if np.linalg.norm(v) < 1e-3:      # analytically-zero grads (biases/gammas feeding a BN)
+            assert np.abs(S.P["b." + k].grad.numpy()).max() < 1e-3, k
+        else:
+            assert relnorm(S.P["b." + k].grad, v) < 2e-4, k
+    for k, v in g["state_after"].items():
+        if "running" in k:
+            close(S.B["b." + k], v, 1e-5, 1e-6, k)
+    assert S.used == set(S.P.keys())
+
+
+# ---------------------------------------------------------------------------------------------
+def cfg_from_args(a, ndim=None):
+    nd = 3 if a["datadim"] == "3d" else 2
+    return {"ndim": nd, "filters": a["filters"], "skip": a["skip"], "upsample": a["upsample"],
+            "act": a["activation"], "last_act": a["last_activation"], "net": a["net"]}
+
+
+NETS = ["net_mulresunet3d_tiny_trilinear_mae", "net_mulresunet3d_tiny_nearest_mse", "net_mulresunet3d_tiny_odd",
+        "net_skip3d_tiny", "net_mulresunet2d_tiny", "net_mulresunet25d_tiny"]
+
+
+def _load_net_case(g):
+    a = jstr(g["args"])
+    cfg = cfg_from_args(a)
+    img, mask = g["image"], g["mask"]
+    perm = (img.ndim - 1,) + tuple(range(img.ndim - 1))        # main.py:131-135
+    img_t = T(np.transpose(img, perm)[None])
+    mask_t = T(np.transpose(mask, perm)[None])
+    return a, cfg, img_t, mask_t
+
+
+@pytest.mark.parametrize("name", NETS)
+def test_net_iteration0(golden, name):
+    """Iteration 0: loss/SNR/PCORR and out_best given identical theta and input (tight)."""
+    g = golden(name)
+    a, cfg, img, mask = _load_net_case(g)
+    S = O.NetState(g["init_state"])
+    h = O.optimize(S, cfg, T(g["z"]), img, mask, 1, lr=a["lr"], loss_kind=a["loss"], net_inputs=g["net_inputs"])
+    assert S.used == set(S.P.keys())
+    assert abs(h["loss"][0] - g["loss"][0]) <= 2e-6 * abs(g["loss"][0])
+    assert abs(h["snr"][0] - g["snr"][0]) <= 1e-4
+    assert abs(h["pcorr"][0] - g["pcorr"][0]) <= 1e-5
+
+
+@pytest.mark.parametrize("name", NETS)
+def test_net_trajectory(golden, name):
+    """K-iteration trajectory on the tiny nets with the reference's own per-iteration inputs."""
+    g = golden(name)
+    a, cfg, img, mask = _load_net_case(g)
+    S = O.NetState(g["init_state"])
+    K = len(g["loss"])
+    h = O.optimize(S, cfg, T(g["z"]), img, mask, K, lr=a["lr"], loss_kind=a["loss"], net_inputs=g["net_inputs"])
+    np.testing.assert_allclose(h["loss"], g["loss"], rtol=2e-3)
+    np.testing.assert_allclose(h["snr"], g["snr"], atol=5e-2)
+    np.testing.assert_allclose(h["pcorr"], g["pcorr"], atol=5e-3)
+    assert np.argmin(h["loss"]) == np.argmin(g["loss"])
+    ob = h["out_best"].numpy()
+    ob = ob.squeeze() if ob.ndim > 4 else ob[0].transpose(1, 2, 0)     # main.py:175-176
+    assert ob.shape == g["out_best"].shape
+    assert relnorm(ob, g["out_best"]) < 5e-3
+    # weights that carry real gradient agree; dead conv biases may flip sign
+    fin = S.state_dict()
+    for k, v in g["final_state"].items():
+        if k.endswith("weight") and v.ndim > 1:
+            assert relnorm(fin[k], v) < 5e-2, k
+
+
+def test_structure_full_nets(golden):
+    """Key derivation for the full-depth nets: every reference key is consumed by the restated forward."""
+    g = golden("structure")
+    cases = {
+        "mulresunet3d_default": ({"ndim": 3, "filters": [16, 32, 64, 128, 256], "skip": [16, 32, 64, 128],
+                                  "upsample": "nearest"}, (1, 64, 16, 16, 16), 5923614),
+        "mulresunet2d_default": ({"ndim": 2, "filters": [16, 32, 64, 128, 256], "skip": [16, 32, 64, 128],
+                                  "upsample": "bilinear"}, (1, 64, 32, 32), 2186704),
+        "mulresunet25d_c8": ({"ndim": 2, "filters": [16, 32, 64, 128, 256], "skip": [16, 32, 64, 128],
+                              "upsample": "nearest"}, (1, 64, 32, 32), 2186886),
+        "skip3d_a12": ({"ndim": 3, "net": "skip", "filters": [16, 32, 64, 128, 128], "skip": [4] * 5,
+                        "upsample": "nearest"}, (1, 64, 32, 32, 32), 3049845),
+        "mulresunet3d_noskip": ({"ndim": 3, "filters": [4, 8, 16], "skip": [0, 4], "upsample": "nearest"},
+                                (1, 64, 8, 8, 8), None),
+    }
+    gen = torch.Generator().manual_seed(0)
+    for tag, (cfg, xshape, nparams) in cases.items():
+        keys = jstr(g[tag]["keys"])
+        sd = {}
+        for k, shp in keys:
+            if k.endswith("num_batches_tracked"):
+                sd[k] = np.zeros((), np.int64)
+            elif k.endswith("running_var"):
+                sd[k] = np.ones(shp, np.float32)
+            else:
+                sd[k] = (torch.randn(shp, generator=gen) * 0.1).numpy()
+        S = O.NetState(sd, requires_grad=False)
+        assert sum(p.numel() for p in S.params()) == int(g[tag]["num_params"])
+        if nparams is not None:
+            assert int(g[tag]["num_params"]) == nparams
+        with torch.no_grad():
+            y = O.net_forward(S, torch.randn(xshape, generator=gen), cfg)
+        assert y.shape[2:] == xshape[2:]
+        assert S.used == set(S.P.keys()), tag
+
+
+# ---------------------------------------------------------------------------------------------
+def test_patches(golden):
+    g = golden("host")["pe"]
+    for tag, c in g.items():
+        dim, stride = tuple(c["dim"]), tuple(c["stride"])
+        pa = O.extract_patches_nd(c["vol"], dim, stride)
+        np.testing.assert_array_equal(pa, c["patches"])
+        assert O.patch_grid(c["vol"].shape, dim, stride) == tuple(c["array_shape"][:len(dim)])
+        assert int(np.prod(O.patch_grid(c["vol"].shape, dim, stride))) == int(c["count"])
+        np.testing.assert_allclose(O.reconstruct_nd(c["patches2"], dim, stride), c["recon2"], rtol=1e-14, atol=1e-14)
+        rec = O.reconstruct_nd(pa, dim, stride)
+        cs = tuple(c["cropped_shape"])
+        assert rec.shape == cs
+        np.testing.assert_allclose(rec, c["vol"][tuple(slice(0, n) for n in cs)], rtol=1e-14, atol=1e-14)
+
+
+def test_host_misc(golden):
+    g = golden("host")
+    np.testing.assert_array_equal(O.nan_to_binary_mask(g["bool2bin"]["in"]), g["bool2bin"]["out"])
+    m = g["metrics"]
+    assert abs(O.snr(T(m["out"]), T(m["tgt"])).item() - float(m["snr"])) < 1e-5
+    assert abs(O.pcorr(T(m["out"]), T(m["tgt"])).item() - float(m["pcorr"])) < 1e-6
+    # EarlyStopping
+    es = O.EarlyStop(40, 1.0)
+    got = [es.step(l) for l in g["earlystop"]["losses"]]
+    first = int(np.argmax(g["earlystop"]["stop"]))
+    assert got[:first + 1] == list(g["earlystop"]["stop"][:first + 1])
+    # ReduceLROnPlateau
+    lr0, fac, thr, pat = g["plateau"]["cfg"]
+    sch = O.PlateauLR(lr0, fac, thr, int(pat))
+    lrs = [sch.step(l) for l in g["earlystop"]["losses"]]
+    np.testing.assert_allclose(lrs, g["plateau"]["lr"], rtol=1e-12)
+    # Adam
+    a = g["adam"]
+    p, mm, vv = T(a["p0"]), torch.zeros(37), torch.zeros(37)
+    for k in range(5):
+        p, mm, vv = O.adam_update(p, T(a["grads"][k]), mm, vv, k + 1, 1e-3)
+        np.testing.assert_allclose(p.numpy(), a["traj"][k], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(mm.numpy(), a["m"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(vv.numpy(), a["v"], rtol=1e-6, atol=1e-20)
+    # lines known answer (proof_of_concept_2D.ipynb:308: "std of coarse data is 3.62e-02")
+    ln = g["lines"]
+    std = torch.std(T(ln["original"]) * T(ln["mask"].astype(np.float32))).item()
+    assert "%.2e" % std == "3.62e-02"
+    assert abs(std - float(ln["std"])) < 1e-7
+    assert int(ln["kept_traces"]) == 34
