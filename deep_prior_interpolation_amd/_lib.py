@@ -1,0 +1,102 @@
+"""ctypes binding of libdpi_hip.so (C ABI declared in include/dpi_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent, importing
+this module (or the first GPU op) raises.  torch is used only to obtain device pointers and the
+current HIP stream.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdpi_hip.so")
+
+
+class DpiError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("Cin", C.c_int), ("Cout", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("k", C.c_int), ("kd", C.c_int), ("stride", C.c_int)]
+
+
+class AdamTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_Z = C.c_size_t
+_F = C.c_float
+_U64 = C.c_uint64
+_DESC = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes).  Kept in one table so tests can check every symbol of the header is exported.
+SIGNATURES = {
+    "dpi_last_error": (C.c_char_p, []),
+    "dpi_version": (_I, []),
+    "dpi_device_info": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_Z), C.c_char_p, _I]),
+    "dpi_conv_fwd_stat_blocks": (_I, [_DESC]),
+    "dpi_conv_fwd": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P]),
+    "dpi_conv_bwd_data": (_I, [_DESC, _P, _P, _P, _I, _P]),
+    "dpi_conv_bwd_weight_ws_floats": (_Z, [_DESC]),
+    "dpi_conv_bwd_weight": (_I, [_DESC, _P, _P, _P, _P, _P, _Z, _P]),
+    "dpi_stat_blocks": (_I, [_I, _Z]),
+    "dpi_channel_stats": (_I, [_P, _P, _I, _Z, _P, _P]),
+    "dpi_bn_finalize": (_I, [_P, _I, _I, _Z, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "dpi_chain_apply": (_I, [_P, _P, _I, _Z, _P, _P]),
+    "dpi_bn_bwd_reduce": (_I, [_P, _P, _P, _I, _Z, _P, _P]),
+    "dpi_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _Z, _P, _P, _P, _P]),
+    "dpi_lrelu_bwd": (_I, [_P, _P, _F, _Z, _P, _P]),
+    "dpi_add": (_I, [_P, _P, _Z, _P, _P]),
+    "dpi_channel_sum": (_I, [_P, _I, _Z, _P, _P, _P]),
+    "dpi_upsample2x_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "dpi_upsample2x_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "dpi_crop_copy": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "dpi_crop_copy_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "dpi_loss_ws_doubles": (_Z, [_Z]),
+    "dpi_masked_loss": (_I, [_P, _P, _P, _Z, _I, _F, _P, _P, _P, _P]),
+    "dpi_adam_multi": (_I, [_P, _P, _I, _P, _F, _F, _F, _P, _P]),
+    "dpi_noise_add": (_I, [_P, _Z, _F, _U64, _P, _P, _P]),
+    "dpi_fill_normal": (_I, [_P, _Z, _F, _F, _U64, _U64, _P]),
+    "dpi_overlap_add": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
+    "dpi_overlap_normalize": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raises DpiError when it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DpiError("libdpi_hip.so not found at %s — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise DpiError("libdpi_hip.so does not export %s (stale build?)" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().dpi_last_error()
+        raise DpiError("%s failed (%d): %s" % (what, code, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,42 @@
+// Error plumbing and device queries of the C ABI (see include/dpi_hip.h).
+#include <stdarg.h>
+#include <string.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void dpi_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int dpi_check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    dpi_set_error("%s: %s", what, hipGetErrorString(e));
+    return DPI_E_LAUNCH;
+  }
+  return DPI_OK;
+}
+
+extern "C" const char* dpi_last_error(void) { return g_err; }
+extern "C" int dpi_version(void) { return 100; }
+
+extern "C" int dpi_device_info(int device, int* cus, int* lds_bytes, size_t* hbm_bytes, char* name, int name_len) {
+  hipDeviceProp_t p;
+  const hipError_t e = hipGetDeviceProperties(&p, device);
+  if (e != hipSuccess) {
+    dpi_set_error("device_info: %s", hipGetErrorString(e));
+    return DPI_E_LAUNCH;
+  }
+  if (cus) *cus = p.multiProcessorCount;
+  if (lds_bytes) *lds_bytes = (int)p.sharedMemPerBlock;
+  if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+  if (name && name_len > 0) {
+    strncpy(name, p.gcnArchName, name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  return DPI_OK;
+}

@@ -1,0 +1,67 @@
+// Shared device helpers and host-side error plumbing for libdpi_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/dpi_hip.h"
+
+#define DPI_WAVE 64
+
+void dpi_set_error(const char* fmt, ...);
+int dpi_check_launch(const char* what);
+
+#define DPI_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      dpi_set_error(__VA_ARGS__);         \
+      return DPI_E_ARG;                   \
+    }                                     \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
+
+// ---- per-channel load transform ("chain"): T(x) = qs*act(ps*x+pb)+qb -----------------------------
+struct Chain {
+  float ps, pb, slope, qs, qb;
+};
+__device__ __forceinline__ Chain load_chain(const float* __restrict__ chain, int c) {
+  Chain t;
+  if (chain) {
+    const float* p = chain + (size_t)c * DPI_CHAIN_STRIDE;
+    t.ps = p[0]; t.pb = p[1]; t.slope = p[2]; t.qs = p[3]; t.qb = p[4];
+  } else {
+    t.ps = 1.f; t.pb = 0.f; t.slope = 1.f; t.qs = 1.f; t.qb = 0.f;
+  }
+  return t;
+}
+__device__ __forceinline__ float apply_chain(const Chain& t, float x) {
+  float v = fmaf(t.ps, x, t.pb);
+  v = v > 0.f ? v : v * t.slope;
+  return fmaf(t.qs, v, t.qb);
+}
+
+// ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Sum `v` over the whole block; result valid in thread 0.  `sh` needs >= blockDim/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wid] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nw; ++i) r += sh[i];
+  return r;
+}

@@ -1,0 +1,441 @@
+// HBM-bound elementwise / reduction kernels of the hot path: BatchNorm statistics + finalize + apply,
+// BatchNorm backward, LeakyReLU backward, residual add, x2 up-sampling (nearest / linear, with the
+// Concat centre-crop folded in), crop copy.  All reductions are two-stage in double precision with a
+// fixed summation order (deterministic run to run).
+#include "common.h"
+
+namespace {
+
+constexpr int kStatSpan = 16384;   // voxels per block and channel in the streaming reductions
+constexpr int kMaxStatBlocks = 2048;
+
+__host__ __device__ inline size_t stat_span(size_t V, int nblk) {
+  size_t s = (V + nblk - 1) / nblk;
+  return (s + 3) & ~(size_t)3;   // keep float4 alignment of every span start
+}
+
+// ---- per-channel {sum, sum^2} of T(x) ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, const float* __restrict__ chain,
+                                                            int C, size_t V, int nblk, double* __restrict__ partials) {
+  const int c = blockIdx.y, b = blockIdx.x;
+  const size_t span = stat_span(V, nblk);
+  const size_t beg = (size_t)b * span, end = beg + span < V ? beg + span : V;
+  const float* __restrict__ xc = x + (size_t)c * V;
+  const Chain t = load_chain(chain, c);
+  double s = 0.0, q = 0.0;
+  const bool vec = (V & 3) == 0;
+  for (size_t i = beg + (size_t)threadIdx.x * 4; i < end; i += 1024) {
+    float v[4];
+    if (vec) {
+      const float4 f = *reinterpret_cast<const float4*>(xc + i);
+      v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = i + k < end ? xc[i + k] : 0.f;
+    }
+    float ls = 0.f;
+    double lq = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i + k < end) {
+        const float y = apply_chain(t, v[k]);
+        ls += y;
+        lq += (double)y * y;
+      }
+    s += ls; q += lq;
+  }
+  __shared__ double sh[8];
+  const double S = block_sum(s, sh);
+  const double Q = block_sum(q, sh + 4);
+  if (threadIdx.x == 0) {
+    partials[((size_t)b * C + c) * 2 + 0] = S;
+    partials[((size_t)b * C + c) * 2 + 1] = Q;
+  }
+}
+
+// ---- finalize: one wave per channel, fixed-order reduction of the block partials ----------------------------
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restrict__ partials, int nblk, int C, double count,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, float momentum, float slope, float* running_mean,
+                                                         float* running_var, int64_t* nbt, float* __restrict__ mean_invstd,
+                                                         float* __restrict__ chain_out) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int b = lane; b < nblk; b += 64) {
+    s += partials[((size_t)b * C + c) * 2 + 0];
+    q += partials[((size_t)b * C + c) * 2 + 1];
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if (lane == 0) {
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float meanf = (float)mean;
+    if (mean_invstd) { mean_invstd[c] = meanf; mean_invstd[C + c] = invstd; }
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+    if (running_var) {
+      const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+    if (nbt && c == 0) *nbt += 1;
+    if (chain_out) {
+      const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+      const float a = g * invstd;
+      float* o = chain_out + (size_t)c * DPI_CHAIN_STRIDE;
+      o[0] = a; o[1] = bt - meanf * a; o[2] = slope; o[3] = 1.f; o[4] = 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void chain_apply_kernel(const float* __restrict__ x, const float* __restrict__ chain, size_t V,
+                                                          float* __restrict__ y) {
+  const int c = blockIdx.y;
+  const Chain t = load_chain(chain, c);
+  const float* __restrict__ xc = x + (size_t)c * V;
+  float* __restrict__ yc = y + (size_t)c * V;
+  const bool vec = (V & 3) == 0;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < V; i += (size_t)gridDim.x * 1024) {
+    if (vec) {
+      float4 f = *reinterpret_cast<const float4*>(xc + i);
+      f.x = apply_chain(t, f.x); f.y = apply_chain(t, f.y); f.z = apply_chain(t, f.z); f.w = apply_chain(t, f.w);
+      *reinterpret_cast<float4*>(yc + i) = f;
+    } else {
+      for (int k = 0; k < 4 && i + k < V; ++k) yc[i + k] = apply_chain(t, xc[i + k]);
+    }
+  }
+}
+
+// ---- BatchNorm backward ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean_invstd, int C, size_t V, int nblk,
+                                                            double* __restrict__ partials) {
+  const int c = blockIdx.y, b = blockIdx.x;
+  const size_t span = stat_span(V, nblk);
+  const size_t beg = (size_t)b * span, end = beg + span < V ? beg + span : V;
+  const float mean = mean_invstd[c], invstd = mean_invstd[C + c];
+  const float* __restrict__ xc = x + (size_t)c * V;
+  const float* __restrict__ gc = dy + (size_t)c * V;
+  double s = 0.0, q = 0.0;
+  const bool vec = (V & 3) == 0;
+  for (size_t i = beg + (size_t)threadIdx.x * 4; i < end; i += 1024) {
+    float xv[4], gv[4];
+    if (vec) {
+      const float4 f = *reinterpret_cast<const float4*>(xc + i);
+      const float4 g = *reinterpret_cast<const float4*>(gc + i);
+      xv[0] = f.x; xv[1] = f.y; xv[2] = f.z; xv[3] = f.w;
+      gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { xv[k] = i + k < end ? xc[i + k] : 0.f; gv[k] = i + k < end ? gc[i + k] : 0.f; }
+    }
+    float ls = 0.f, lq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i + k < end) { ls += gv[k]; lq = fmaf(gv[k], (xv[k] - mean) * invstd, lq); }
+    s += ls; q += lq;
+  }
+  __shared__ double sh[8];
+  const double S = block_sum(s, sh);
+  const double Q = block_sum(q, sh + 4);
+  if (threadIdx.x == 0) {
+    partials[((size_t)b * C + c) * 2 + 0] = S;
+    partials[((size_t)b * C + c) * 2 + 1] = Q;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
+                                                           const double* __restrict__ partials, int nblk, int C, size_t V,
+                                                           float* __restrict__ dx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+  const int c = blockIdx.y;
+  __shared__ double tot[2];
+  if (threadIdx.x < 64) {
+    double s = 0.0, q = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) {
+      s += partials[((size_t)b * C + c) * 2 + 0];
+      q += partials[((size_t)b * C + c) * 2 + 1];
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (threadIdx.x == 0) { tot[0] = s; tot[1] = q; }
+  }
+  __syncthreads();
+  const float mean = mean_invstd[c], invstd = mean_invstd[C + c];
+  const float a = (gamma ? gamma[c] : 1.f) * invstd;
+  const float k1 = (float)(tot[0] / (double)V), k2 = (float)(tot[1] / (double)V);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (dgamma) dgamma[c] = (float)tot[1];
+    if (dbeta) dbeta[c] = (float)tot[0];
+  }
+  const float* __restrict__ xc = x + (size_t)c * V;
+  const float* __restrict__ gc = dy + (size_t)c * V;
+  float* __restrict__ oc = dx + (size_t)c * V;
+  const bool vec = (V & 3) == 0;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < V; i += (size_t)gridDim.x * 1024) {
+    if (vec) {
+      const float4 f = *reinterpret_cast<const float4*>(xc + i);
+      const float4 g = *reinterpret_cast<const float4*>(gc + i);
+      float4 o;
+      o.x = a * (g.x - k1 - (f.x - mean) * invstd * k2);
+      o.y = a * (g.y - k1 - (f.y - mean) * invstd * k2);
+      o.z = a * (g.z - k1 - (f.z - mean) * invstd * k2);
+      o.w = a * (g.w - k1 - (f.w - mean) * invstd * k2);
+      *reinterpret_cast<float4*>(oc + i) = o;
+    } else {
+      for (int k = 0; k < 4 && i + k < V; ++k) oc[i + k] = a * (gc[i + k] - k1 - (xc[i + k] - mean) * invstd * k2);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float slope,
+                                                        size_t n, float* __restrict__ dx) {
+  const bool vec = (n & 3) == 0;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+    if (vec) {
+      const float4 f = *reinterpret_cast<const float4*>(x + i);
+      float4 g = *reinterpret_cast<const float4*>(dy + i);
+      g.x = f.x > 0.f ? g.x : g.x * slope; g.y = f.y > 0.f ? g.y : g.y * slope;
+      g.z = f.z > 0.f ? g.z : g.z * slope; g.w = f.w > 0.f ? g.w : g.w * slope;
+      *reinterpret_cast<float4*>(dx + i) = g;
+    } else {
+      for (int k = 0; k < 4 && i + k < n; ++k) dx[i + k] = x[i + k] > 0.f ? dy[i + k] : dy[i + k] * slope;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                  float* __restrict__ y) {
+  const bool vec = (n & 3) == 0;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+    if (vec) {
+      const float4 f = *reinterpret_cast<const float4*>(a + i);
+      const float4 g = *reinterpret_cast<const float4*>(b + i);
+      *reinterpret_cast<float4*>(y + i) = make_float4(f.x + g.x, f.y + g.y, f.z + g.z, f.w + g.w);
+    } else {
+      for (int k = 0; k < 4 && i + k < n; ++k) y[i + k] = a[i + k] + b[i + k];
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void channel_sum_final_kernel(const double* __restrict__ partials, int nblk, int C,
+                                                               float* __restrict__ out) {
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 64) s += partials[((size_t)b * C + c) * 2];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[c] = (float)s;
+}
+
+// ---- x2 up-sampling ------------------------------------------------------------------------------------------
+// align_corners=False, scale 2: src = (o + .5)/2 - .5 clamped at 0  ->  even o: (.25, .75) on (o/2-1, o/2);
+// odd o: (.75, .25) on (o/2, o/2+1); indices edge-clamped.
+__device__ __forceinline__ void lin_src(int o, int n, int& i0, int& i1, float& w0, float& w1) {
+  const int h = o >> 1;
+  if (o & 1) { i0 = h; i1 = min(h + 1, n - 1); w0 = .75f; w1 = .25f; }
+  else { i0 = max(h - 1, 0); i1 = h; w0 = (h == 0) ? 0.f : .25f; w1 = (h == 0) ? 1.f : .75f; }
+}
+
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, const float* __restrict__ chain, int D, int H,
+                                                           int W, int Do, int Ho, int Wo, int linear, int scale_d,
+                                                           float* __restrict__ y) {
+  const int c = blockIdx.y;
+  const size_t Vo = (size_t)Do * Ho * Wo, V = (size_t)D * H * W;
+  const Chain t = load_chain(chain, c);
+  const float* __restrict__ xc = x + (size_t)c * V;
+  float* __restrict__ yc = y + (size_t)c * Vo;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < Vo; i += (size_t)gridDim.x * 256) {
+    const int ow = i % Wo, oh = (i / Wo) % Ho, od = i / ((size_t)Wo * Ho);
+    float r;
+    if (!linear) {
+      const int id = scale_d ? od >> 1 : od;
+      r = apply_chain(t, xc[((size_t)id * H + (oh >> 1)) * W + (ow >> 1)]);
+    } else {
+      int d0, d1, h0, h1, w0, w1;
+      float a0, a1, b0, b1, c0, c1;
+      if (scale_d) lin_src(od, D, d0, d1, a0, a1); else { d0 = d1 = od; a0 = 1.f; a1 = 0.f; }
+      lin_src(oh, H, h0, h1, b0, b1);
+      lin_src(ow, W, w0, w1, c0, c1);
+      auto at = [&](int d, int h, int w) { return apply_chain(t, xc[((size_t)d * H + h) * W + w]); };
+      const float p0 = b0 * (c0 * at(d0, h0, w0) + c1 * at(d0, h0, w1)) + b1 * (c0 * at(d0, h1, w0) + c1 * at(d0, h1, w1));
+      r = a0 * p0;
+      if (scale_d)
+        r += a1 * (b0 * (c0 * at(d1, h0, w0) + c1 * at(d1, h0, w1)) + b1 * (c0 * at(d1, h1, w0) + c1 * at(d1, h1, w1)));
+    }
+    yc[i] = r;
+  }
+}
+
+// weight with which output index o reads input index i along one axis of length n
+__device__ __forceinline__ float lin_wt(int o, int i, int n) {
+  int i0, i1; float w0, w1;
+  lin_src(o, n, i0, i1, w0, w1);
+  return (i0 == i ? w0 : 0.f) + (i1 == i ? w1 : 0.f);
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, int D, int H, int W, int Do, int Ho, int Wo,
+                                                           int linear, int scale_d, float* __restrict__ dx) {
+  const int c = blockIdx.y;
+  const size_t Vo = (size_t)Do * Ho * Wo, V = (size_t)D * H * W;
+  const float* __restrict__ gc = dy + (size_t)c * Vo;
+  float* __restrict__ oc = dx + (size_t)c * V;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
+    const int iw = i % W, ih = (i / W) % H, id = i / ((size_t)W * H);
+    float acc = 0.f;
+    if (!linear) {
+      const int dlo = scale_d ? 2 * id : id, dhi = scale_d ? 2 * id + 1 : id;
+      for (int od = dlo; od <= dhi && od < Do; ++od)
+        for (int oh = 2 * ih; oh <= 2 * ih + 1 && oh < Ho; ++oh)
+          for (int ow = 2 * iw; ow <= 2 * iw + 1 && ow < Wo; ++ow) acc += gc[((size_t)od * Ho + oh) * Wo + ow];
+    } else {
+      const int dlo = scale_d ? max(2 * id - 1, 0) : id, dhi = scale_d ? min(2 * id + 2, Do - 1) : id;
+      for (int od = dlo; od <= dhi; ++od) {
+        const float wd = scale_d ? lin_wt(od, id, D) : 1.f;
+        if (wd == 0.f) continue;
+        for (int oh = max(2 * ih - 1, 0); oh <= min(2 * ih + 2, Ho - 1); ++oh) {
+          const float wh = lin_wt(oh, ih, H);
+          if (wh == 0.f) continue;
+          for (int ow = max(2 * iw - 1, 0); ow <= min(2 * iw + 2, Wo - 1); ++ow) {
+            const float ww = lin_wt(ow, iw, W);
+            if (ww != 0.f) acc = fmaf(wd * wh * ww, gc[((size_t)od * Ho + oh) * Wo + ow], acc);
+          }
+        }
+      }
+    }
+    oc[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void crop_copy_kernel(const float* __restrict__ x, int D, int H, int W, int od, int oh, int ow,
+                                                        int Do, int Ho, int Wo, float* __restrict__ y, int adjoint) {
+  // forward: y[c][Do][Ho][Wo] = x[c][od+.., oh+.., ow+..]; adjoint: x-shaped output, zero outside the window
+  const int c = blockIdx.y;
+  const size_t V = (size_t)D * H * W, Vo = (size_t)Do * Ho * Wo;
+  if (!adjoint) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < Vo; i += (size_t)gridDim.x * 256) {
+      const int w = i % Wo, h = (i / Wo) % Ho, d = i / ((size_t)Wo * Ho);
+      y[(size_t)c * Vo + i] = x[(size_t)c * V + ((size_t)(d + od) * H + h + oh) * W + w + ow];
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
+      const int w = i % W, h = (i / W) % H, d = i / ((size_t)W * H);
+      const int cd = d - od, ch = h - oh, cw = w - ow;
+      const bool in = cd >= 0 && cd < Do && ch >= 0 && ch < Ho && cw >= 0 && cw < Wo;
+      y[(size_t)c * V + i] = in ? x[(size_t)c * Vo + ((size_t)cd * Ho + ch) * Wo + cw] : 0.f;
+    }
+  }
+}
+
+inline unsigned ew_blocks(size_t n_vec4_threads) {
+  size_t b = cdivz(n_vec4_threads, 256);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int dpi_stat_blocks(int C, size_t V) {
+  if (C <= 0 || V == 0) return 0;
+  size_t n = cdivz(V, kStatSpan);
+  if (n > kMaxStatBlocks) n = kMaxStatBlocks;
+  return (int)n;
+}
+
+extern "C" int dpi_channel_stats(const float* x, const float* chain, int C, size_t V, double* partials, void* stream) {
+  DPI_REQUIRE(x && partials && C > 0 && V > 0, "channel_stats: bad argument");
+  const int nblk = dpi_stat_blocks(C, V);
+  channel_stats_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(x, chain, C, V, nblk, partials);
+  return dpi_check_launch("channel_stats");
+}
+
+extern "C" int dpi_bn_finalize(const double* partials, int nblk, int C, size_t count, const float* gamma, const float* beta,
+                               float eps, float momentum, float slope, float* running_mean, float* running_var,
+                               int64_t* num_batches_tracked, float* mean_invstd, float* chain_out, void* stream) {
+  DPI_REQUIRE(partials && nblk > 0 && C > 0 && count > 0, "bn_finalize: bad argument");
+  bn_finalize_kernel<<<C, 64, 0, (hipStream_t)stream>>>(partials, nblk, C, (double)count, gamma, beta, eps, momentum, slope,
+                                                        running_mean, running_var, num_batches_tracked, mean_invstd, chain_out);
+  return dpi_check_launch("bn_finalize");
+}
+
+extern "C" int dpi_chain_apply(const float* x, const float* chain, int C, size_t V, float* y, void* stream) {
+  DPI_REQUIRE(x && y && C > 0 && V > 0, "chain_apply: bad argument");
+  chain_apply_kernel<<<dim3(ew_blocks(cdivz(V, 4)), C), 256, 0, (hipStream_t)stream>>>(x, chain, V, y);
+  return dpi_check_launch("chain_apply");
+}
+
+extern "C" int dpi_bn_bwd_reduce(const float* dy, const float* x, const float* mean_invstd, int C, size_t V, double* partials,
+                                 void* stream) {
+  DPI_REQUIRE(dy && x && mean_invstd && partials && C > 0 && V > 0, "bn_bwd_reduce: bad argument");
+  const int nblk = dpi_stat_blocks(C, V);
+  bn_bwd_reduce_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, C, V, nblk, partials);
+  return dpi_check_launch("bn_bwd_reduce");
+}
+
+extern "C" int dpi_bn_bwd_apply(const float* dy, const float* x, const float* mean_invstd, const float* gamma,
+                                const double* partials, int nblk, int C, size_t V, float* dx, float* dgamma, float* dbeta,
+                                void* stream) {
+  DPI_REQUIRE(dy && x && mean_invstd && partials && dx && C > 0 && V > 0 && nblk > 0, "bn_bwd_apply: bad argument");
+  bn_bwd_apply_kernel<<<dim3(ew_blocks(cdivz(V, 4)), C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, partials, nblk,
+                                                                                      C, V, dx, dgamma, dbeta);
+  return dpi_check_launch("bn_bwd_apply");
+}
+
+extern "C" int dpi_lrelu_bwd(const float* dy, const float* x, float slope, size_t n, float* dx, void* stream) {
+  DPI_REQUIRE(dy && x && dx && n > 0, "lrelu_bwd: bad argument");
+  lrelu_bwd_kernel<<<ew_blocks(cdivz(n, 4)), 256, 0, (hipStream_t)stream>>>(dy, x, slope, n, dx);
+  return dpi_check_launch("lrelu_bwd");
+}
+
+extern "C" int dpi_add(const float* a, const float* b, size_t n, float* y, void* stream) {
+  DPI_REQUIRE(a && b && y && n > 0, "add: bad argument");
+  add_kernel<<<ew_blocks(cdivz(n, 4)), 256, 0, (hipStream_t)stream>>>(a, b, n, y);
+  return dpi_check_launch("add");
+}
+
+extern "C" int dpi_channel_sum(const float* x, int C, size_t V, double* ws, float* out, void* stream) {
+  DPI_REQUIRE(x && ws && out && C > 0 && V > 0, "channel_sum: bad argument");
+  const int nblk = dpi_stat_blocks(C, V);
+  channel_stats_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(x, nullptr, C, V, nblk, ws);
+  if (int e = dpi_check_launch("channel_sum.stats")) return e;
+  channel_sum_final_kernel<<<C, 64, 0, (hipStream_t)stream>>>(ws, nblk, C, out);
+  return dpi_check_launch("channel_sum.final");
+}
+
+extern "C" int dpi_upsample2x_fwd(const float* x, const float* chain, int C, int D, int H, int W, int Do, int Ho, int Wo,
+                                  int linear, float* y, void* stream) {
+  DPI_REQUIRE(x && y && C > 0 && D > 0 && H > 0 && W > 0, "upsample_fwd: bad argument");
+  const int scale_d = !(D == 1 && Do == 1);
+  DPI_REQUIRE(Do >= 1 && Ho >= 1 && Wo >= 1 && Do <= (scale_d ? 2 * D : 1) && Ho <= 2 * H && Wo <= 2 * W,
+              "upsample_fwd: output (%d,%d,%d) exceeds 2x input (%d,%d,%d)", Do, Ho, Wo, D, H, W);
+  const size_t Vo = (size_t)Do * Ho * Wo;
+  upsample_fwd_kernel<<<dim3(ew_blocks(Vo), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, linear, scale_d, y);
+  return dpi_check_launch("upsample_fwd");
+}
+
+extern "C" int dpi_upsample2x_bwd(const float* dy, int C, int D, int H, int W, int Do, int Ho, int Wo, int linear, float* dx,
+                                  void* stream) {
+  DPI_REQUIRE(dy && dx && C > 0 && D > 0 && H > 0 && W > 0, "upsample_bwd: bad argument");
+  const int scale_d = !(D == 1 && Do == 1);
+  const size_t V = (size_t)D * H * W;
+  upsample_bwd_kernel<<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, linear, scale_d, dx);
+  return dpi_check_launch("upsample_bwd");
+}
+
+extern "C" int dpi_crop_copy(const float* x, int C, int D, int H, int W, int od, int oh, int ow, int Do, int Ho, int Wo, float* y,
+                             void* stream) {
+  DPI_REQUIRE(x && y && od >= 0 && oh >= 0 && ow >= 0 && od + Do <= D && oh + Ho <= H && ow + Wo <= W, "crop_copy: bad window");
+  crop_copy_kernel<<<dim3(ew_blocks((size_t)Do * Ho * Wo), C), 256, 0, (hipStream_t)stream>>>(x, D, H, W, od, oh, ow, Do, Ho, Wo,
+                                                                                            y, 0);
+  return dpi_check_launch("crop_copy");
+}
+
+extern "C" int dpi_crop_copy_bwd(const float* dy, int C, int D, int H, int W, int od, int oh, int ow, int Do, int Ho, int Wo,
+                                 float* dx, void* stream) {
+  DPI_REQUIRE(dy && dx && od >= 0 && oh >= 0 && ow >= 0 && od + Do <= D && oh + Ho <= H && ow + Wo <= W, "crop_copy_bwd: bad window");
+  crop_copy_kernel<<<dim3(ew_blocks((size_t)D * H * W), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, od, oh, ow, Do, Ho, Wo, dx,
+                                                                                         1);
+  return dpi_check_launch("crop_copy_bwd");
+}

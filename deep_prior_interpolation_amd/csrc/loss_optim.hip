@@ -1,0 +1,211 @@
+// Masked L1/MSE loss with fused gradient and SNR/PCORR sums, multi-tensor Adam, Philox input noise,
+// overlap-add patch reassembly.
+#include "common.h"
+
+namespace {
+
+constexpr int kLossBlocks = 1024;
+
+// partial layout per block: {sum|d| or d^2, sum t^2, sum (t-o)^2, sum o, sum t, sum o^2, sum o*t, unused}
+__global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restrict__ out, const float* __restrict__ img,
+                                                           const float* __restrict__ mask, size_t n, int kind, float gscale,
+                                                           float* __restrict__ dout, double* __restrict__ ws) {
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  const float inv_n = gscale / (float)n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float o = out[i], t = img[i], m = mask[i];
+    const float d = o * m - t * m;
+    float g;
+    if (kind == 1) { acc[0] += (double)d * d; g = 2.f * d * m * inv_n; }
+    else { acc[0] += fabsf(d); g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * m * inv_n; }
+    if (dout) dout[i] = g;
+    const float e = t - o;
+    acc[1] += (double)t * t; acc[2] += (double)e * e; acc[3] += o; acc[4] += t;
+    acc[5] += (double)o * o; acc[6] += (double)o * t;
+  }
+  __shared__ double sh[4];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const double r = block_sum(acc[k], sh);
+    if (threadIdx.x == 0) ws[(size_t)blockIdx.x * 8 + k] = r;
+  }
+}
+
+__global__ __launch_bounds__(64) void loss_final_kernel(const double* __restrict__ ws, int nblk, double n, double* __restrict__ res) {
+  double acc[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += ws[(size_t)b * 8 + k];
+    acc[k] = wave_sum(s);
+  }
+  if (threadIdx.x == 0) {
+    const double loss = acc[0] / n;
+    const double snr = 10.0 * log10(acc[1] / acc[2]);
+    const double mo = acc[3] / n, mt = acc[4] / n;
+    const double cov = acc[6] - n * mo * mt;
+    const double vt = acc[1] - n * mt * mt, vo = acc[5] - n * mo * mo;
+    res[0] = loss; res[1] = snr; res[2] = cov / (sqrt(vt) * sqrt(vo));
+    res[3] = acc[1]; res[4] = acc[2]; res[5] = acc[3]; res[6] = acc[4]; res[7] = acc[5];
+  }
+}
+
+// ---- Adam -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(const dpi_adam_tensor* __restrict__ tensors, const int64_t* __restrict__ sizes,
+                                                   const float* __restrict__ step_lr, float beta1, float beta2, float eps,
+                                                   const int* __restrict__ active) {
+  if (active && *active == 0) return;
+  const dpi_adam_tensor t = tensors[blockIdx.y];
+  const size_t n = (size_t)sizes[blockIdx.y];
+  const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  const float step = step_lr[0], lr = step_lr[1];
+  const float bc1 = 1.f - powf(beta1, step);
+  const float bc2s = sqrtf(1.f - powf(beta2, step));
+  const float step_size = lr / bc1;
+  for (size_t i = i0; i < n; i += (size_t)gridDim.x * 1024) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i + k < n) {
+        const float g = t.g[i + k];
+        const float m = beta1 * t.m[i + k] + (1.f - beta1) * g;
+        const float v = beta2 * t.v[i + k] + (1.f - beta2) * g * g;
+        t.m[i + k] = m;
+        t.v[i + k] = v;
+        const float denom = sqrtf(v) / bc2s + eps;
+        t.p[i + k] -= step_size * (m / denom);
+      }
+  }
+}
+
+// ---- Philox4x32-10 ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4(uint64_t ctr, uint64_t stream_id, uint64_t seed, float (&z)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  // Box-Muller on two pairs of uniforms in (0,1]
+  const float u0 = ((c[0] >> 8) + 1) * (1.f / 16777216.f), u1 = (c[1] >> 8) * (1.f / 16777216.f);
+  const float u2 = ((c[2] >> 8) + 1) * (1.f / 16777216.f), u3 = (c[3] >> 8) * (1.f / 16777216.f);
+  const float r0 = sqrtf(-2.f * __logf(u0)), r1 = sqrtf(-2.f * __logf(u2));
+  float s0, c0, s1, c1;
+  __sincosf(6.283185307179586f * u1, &s0, &c0);
+  __sincosf(6.283185307179586f * u3, &s1, &c1);
+  z[0] = r0 * c0; z[1] = r0 * s0; z[2] = r1 * c1; z[3] = r1 * s1;
+}
+
+__global__ __launch_bounds__(256) void noise_kernel(const float* __restrict__ zin, size_t n, float mean, float std, uint64_t seed,
+                                                    const uint64_t* __restrict__ step_ptr, uint64_t stream_id,
+                                                    float* __restrict__ out) {
+  const uint64_t sid = step_ptr ? *step_ptr : stream_id;
+  const bool vec = (n & 3) == 0;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q * 4 < n; q += (size_t)gridDim.x * 256) {
+    float z[4];
+    philox4(q, sid, seed, z);
+    const size_t i = q * 4;
+    if (vec) {
+      float4 b = zin ? *reinterpret_cast<const float4*>(zin + i) : make_float4(mean, mean, mean, mean);
+      b.x = fmaf(std, z[0], b.x); b.y = fmaf(std, z[1], b.y); b.z = fmaf(std, z[2], b.z); b.w = fmaf(std, z[3], b.w);
+      *reinterpret_cast<float4*>(out + i) = b;
+    } else {
+      for (int k = 0; k < 4 && i + k < n; ++k) out[i + k] = fmaf(std, z[k], zin ? zin[i + k] : mean);
+    }
+  }
+}
+
+// ---- overlap-add -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ patch, int pd, int ph, int pw, int od, int oh, int ow,
+                                                          float* __restrict__ acc, int D, int H, int W) {
+  const size_t n = (size_t)pd * ph * pw;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int w = i % pw, h = (i / pw) % ph, d = i / ((size_t)pw * ph);
+    acc[((size_t)(od + d) * H + oh + h) * W + ow + w] += patch[i];
+  }
+}
+
+// number of windows {k*s : 0 <= k*s <= N-p} covering coordinate x
+__device__ __forceinline__ int hits(int x, int N, int p, int s) {
+  const int kmax = (N - p) / s;
+  int lo = x - p + 1; lo = lo <= 0 ? 0 : (lo + s - 1) / s;
+  int hi = x / s; if (hi > kmax) hi = kmax;
+  return hi >= lo ? hi - lo + 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void overlap_norm_kernel(float* __restrict__ acc, int D, int H, int W, int pd, int ph, int pw, int sd,
+                                                           int sh, int sw, float gain) {
+  const size_t n = (size_t)D * H * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int w = i % W, h = (i / W) % H, d = i / ((size_t)W * H);
+    const int c = hits(d, D, pd, sd) * hits(h, H, ph, sh) * hits(w, W, pw, sw);
+    acc[i] = acc[i] / ((float)c * gain);
+  }
+}
+
+inline unsigned nblocks(size_t n) {
+  size_t b = cdivz(n, 256);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" size_t dpi_loss_ws_doubles(size_t n) { (void)n; return (size_t)kLossBlocks * 8; }
+
+extern "C" int dpi_masked_loss(const float* out, const float* img, const float* mask, size_t n, int kind, float grad_scale,
+                               float* dout, double* ws, double* result, void* stream) {
+  DPI_REQUIRE(out && img && mask && ws && result && n > 0, "masked_loss: bad argument");
+  DPI_REQUIRE(kind == 0 || kind == 1, "masked_loss: kind must be 0 (L1) or 1 (MSE)");
+  size_t nb = cdivz(n, 256 * 8);
+  if (nb > kLossBlocks) nb = kLossBlocks;
+  if (nb < 1) nb = 1;
+  loss_partial_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(out, img, mask, n, kind, grad_scale, dout, ws);
+  if (int e = dpi_check_launch("loss_partial")) return e;
+  loss_final_kernel<<<1, 64, 0, (hipStream_t)stream>>>(ws, (int)nb, (double)n, result);
+  return dpi_check_launch("loss_final");
+}
+
+extern "C" int dpi_adam_multi(const dpi_adam_tensor* tensors, const int64_t* sizes, int ntensors, const float* step_lr,
+                              float beta1, float beta2, float eps, const int* active, void* stream) {
+  DPI_REQUIRE(tensors && sizes && step_lr && ntensors > 0 && ntensors <= 65535, "adam_multi: bad argument");
+  // grid.x is sized for the largest tensor by the caller-independent cap below; blocks past a tensor's end exit.
+  adam_kernel<<<dim3(256, ntensors), 256, 0, (hipStream_t)stream>>>(tensors, sizes, step_lr, beta1, beta2, eps, active);
+  return dpi_check_launch("adam_multi");
+}
+
+extern "C" int dpi_noise_add(const float* z, size_t n, float std, uint64_t seed, const uint64_t* step_ptr, float* out,
+                             void* stream) {
+  DPI_REQUIRE(z && out && n > 0, "noise_add: bad argument");
+  noise_kernel<<<nblocks(cdivz(n, 4)), 256, 0, (hipStream_t)stream>>>(z, n, 0.f, std, seed, step_ptr, 0, out);
+  return dpi_check_launch("noise_add");
+}
+
+extern "C" int dpi_fill_normal(float* out, size_t n, float mean, float std, uint64_t seed, uint64_t stream_id, void* stream) {
+  DPI_REQUIRE(out && n > 0, "fill_normal: bad argument");
+  noise_kernel<<<nblocks(cdivz(n, 4)), 256, 0, (hipStream_t)stream>>>(nullptr, n, mean, std, seed, nullptr, stream_id, out);
+  return dpi_check_launch("fill_normal");
+}
+
+extern "C" int dpi_overlap_add(const float* patch, int pd, int ph, int pw, int od, int oh, int ow, float* acc, int D, int H, int W,
+                               void* stream) {
+  DPI_REQUIRE(patch && acc && od >= 0 && oh >= 0 && ow >= 0 && od + pd <= D && oh + ph <= H && ow + pw <= W,
+              "overlap_add: patch (%d,%d,%d)@(%d,%d,%d) outside volume (%d,%d,%d)", pd, ph, pw, od, oh, ow, D, H, W);
+  overlap_add_kernel<<<nblocks((size_t)pd * ph * pw), 256, 0, (hipStream_t)stream>>>(patch, pd, ph, pw, od, oh, ow, acc, D, H, W);
+  return dpi_check_launch("overlap_add");
+}
+
+extern "C" int dpi_overlap_normalize(float* acc, int D, int H, int W, int pd, int ph, int pw, int sd, int sh, int sw, float gain,
+                                     void* stream) {
+  DPI_REQUIRE(acc && pd <= D && ph <= H && pw <= W && sd > 0 && sh > 0 && sw > 0 && gain != 0.f, "overlap_normalize: bad argument");
+  overlap_norm_kernel<<<nblocks((size_t)D * H * W), 256, 0, (hipStream_t)stream>>>(acc, D, H, W, pd, ph, pw, sd, sh, sw, gain);
+  return dpi_check_launch("overlap_normalize");
+}

@@ -1,0 +1,199 @@
+"""Per-patch deep-prior optimiser — drop-in for reference main.py (Interpolator life-cycle
+load_data -> build_model -> build_input -> optimize -> save_result -> clean, and the `main()` CLI).
+
+Everything inside the iteration runs on the GPU through libdpi_hip.so: input perturbation (Philox),
+network forward/backward (HIP convs / BN / up-sampling), fused masked loss + SNR/PCORR, fused Adam.
+"""
+import os
+import warnings
+from time import time
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from . import utils as u
+from .architectures import get_net
+from .data import extract_patches
+from .optim import DevicePlateau, FusedAdam
+from .parameter import net_args_are_same, parse_arguments
+
+warnings.filterwarnings("ignore")
+
+
+class Interpolator:
+    def __init__(self, args, outpath, device=None, seed=0):
+        self.args = args
+        if device is None:
+            if not torch.cuda.is_available():
+                raise _lib.DpiError("no HIP device: deep_prior_interpolation_amd has no CPU path")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.outpath = outpath
+        self.loss_kind = "mse" if args.loss == "mse" else "mae"
+        self.elapsed = None
+        self.iiter = 0
+        self.iter_to_be_saved = list(range(0, args.epochs, int(args.save_every))) if args.save_every is not None else [0]
+        self.loss_min = None
+        self.outchannel = args.imgchannel
+        self.history = u.History(args.epochs)
+        self.image_name = None
+        self.img = self.img_ = self.mask = self.mask_ = None
+        self.out_best = None
+        self._out_best_dev = None
+        self.zfill = u.ten_digit(args.epochs)
+        self.input_ = None
+        self.add_data_ = None
+        self.add_data_weight = None
+        self.input_list = []
+        self.net = None
+        self.num_params = None
+        self.optimizer = None
+        self.noise_seed = int(seed)
+        self._noise_step = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+    # ------------------------------------------------------------------------------------------
+    def load_data(self, data):
+        """(T,X,Y,C) numpy patch -> (1,C,T,X,Y) fp32 device tensors; returns std of the masked data (main.py:118-139)."""
+        self.image_name = data["name"]
+        self.img = data["image"]
+        self.mask = data["mask"]
+        if self.mask.shape != self.img.shape:
+            raise ValueError("The loaded mask shape has to be", self.img.shape)
+        perm = (self.img.ndim - 1,) + tuple(range(self.img.ndim - 1))
+        to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(np.transpose(a, perm))).unsqueeze(0).float().to(self.device)
+        self.img_ = to_dev(self.img)
+        self.mask_ = to_dev(self.mask)
+        return torch.std(self.img_ * self.mask_).item()
+
+    def build_model(self, netpath=None):
+        if self.outchannel is None:
+            self.outchannel = self.img_.shape[1]
+        if len(self.args.netdir) != 0:
+            saved = u.read_args(os.path.join("./results", *netpath.split("/")[:-1], "args.txt"))
+            assert net_args_are_same(self.args, saved)
+            self.net = get_net(saved, self.outchannel)
+            self.net.load_state_dict(torch.load(os.path.join("./results", netpath), map_location="cpu"))
+        else:
+            self.net = get_net(self.args, self.outchannel)
+            u.init_weights(self.net, self.args.inittype, self.args.initgain)
+        self.net = self.net.float().to(self.device)
+        self.num_params = sum(int(np.prod(list(p.size()))) for p in self.net.parameters())
+
+    def build_input(self):
+        """z = noise_std * N(0,1) of shape (1, inputdepth, *patch) (main.py:59-64).  The noise filters and the
+        data-forgetting term (main.py:66-97) are not on the HIP path yet."""
+        a = self.args
+        if a.filter_noise_with_wavelet or (a.lowpass_fs and a.lowpass_fc) or a.data_forgetting_factor != 0:
+            raise NotImplementedError("input-noise filters / data forgetting are outside the round-1 scope (SURVEY §8f.1)")
+        if a.noise_dist != "n":
+            z = u.get_noise((1, a.inputdepth) + self.img.shape[:-1], a.noise_dist).to(self.device) * a.noise_std
+        else:
+            z = torch.empty((1, a.inputdepth) + self.img.shape[:-1], dtype=torch.float32, device=self.device)
+            _lib.check(_lib.load().dpi_fill_normal(_lib.ptr(z), z.numel(), 0.0, float(a.noise_std), self.noise_seed,
+                                                   0xFFFFFFFF, _lib.stream()), "dpi_fill_normal")
+        self.input_ = z
+
+    # ------------------------------------------------------------------------------------------
+    def perturbed_input(self):
+        """input = z + reg_noise_std * N(0,1), fresh every iteration (main.py:148-150)."""
+        if self.args.reg_noise_std <= 0:
+            return self.input_
+        out = torch.empty_like(self.input_)
+        self._noise_step += 1
+        _lib.check(_lib.load().dpi_noise_add(_lib.ptr(self.input_), out.numel(), float(self.args.reg_noise_std),
+                                             self.noise_seed, _lib.ptr(self._noise_step), _lib.ptr(out), _lib.stream()),
+                   "dpi_noise_add")
+        return out
+
+    def _to_numpy_out(self, out_):
+        """(1,1,T,X,Y) -> (T,X,Y) ; (1,C,H,W) -> (H,W,C)  (main.py:175-176)."""
+        return u.torch_to_np(out_, True) if out_.ndim > 4 else u.torch_to_np(out_, False)[0].transpose((1, 2, 0))
+
+    def optimization_loop(self, net_input=None):
+        input_ = self.perturbed_input() if net_input is None else net_input
+        out_ = self.net(input_)
+        total_loss, metrics = ops.masked_loss(out_, self.img_, self.mask_, self.loss_kind)
+        total_loss.backward()
+        l, s, p = metrics[:3].tolist()          # one read-back for loss, snr, pcorr
+        self.history.append((l, s, p))
+        self.history.lr.append(self.optimizer.param_groups[0]["lr"])
+        if self.iiter == 0 or l <= self.loss_min:
+            self.loss_min = l
+            self._out_best_dev = out_.detach()   # stays on the GPU; copied to the host once, after the loop
+        if self.iiter in self.iter_to_be_saved and self.iiter != 0:
+            np.save(os.path.join(self.outpath, self.image_name.split(".")[0]
+                                 + "_output%s.npy" % str(self.iiter).zfill(self.zfill)), self._to_numpy_out(out_))
+        self.iiter += 1
+        return l
+
+    def optimize(self, net_inputs=None, verbose=True):
+        """Adam loop with optional ReduceLROnPlateau and EarlyStopping (main.py:195-220)."""
+        a = self.args
+        self.optimizer = FusedAdam(self.net.parameters(), lr=a.lr)
+        sched = DevicePlateau(self.optimizer, a.lr_factor, a.lr_thresh, a.lr_patience) if a.reduce_lr else None
+        stopper = u.EarlyStopping(patience=a.earlystop_patience, min_delta=a.earlystop_min_delta, percentage=True)
+        start = time()
+        for j in range(a.epochs):
+            self.optimizer.zero_grad()
+            loss = self.optimization_loop(None if net_inputs is None else net_inputs[j])
+            self.optimizer.step()
+            if sched is not None:
+                sched.step(loss)
+            if verbose:
+                print(self.history.log_message(self.iiter - 1), "\r", end="")
+            if stopper.step(loss):
+                break
+        torch.cuda.synchronize(self.device)
+        self.elapsed = time() - start
+        self.out_best = self._to_numpy_out(self._out_best_dev)
+        if verbose:
+            print("\n" + u.sec2time(self.elapsed))
+
+    # ------------------------------------------------------------------------------------------
+    def save_result(self):
+        np.save(os.path.join(self.outpath, self.image_name + "_run.npy"), {
+            "device": u.get_gpu_name(), "elapsed": u.sec2time(self.elapsed), "outpath": self.outpath,
+            "history": self.history, "mask": self.mask, "image": self.img, "output": self.out_best,
+            "noise": self.input_list,
+        })
+        if self.args.savemodel:
+            torch.save(self.net.state_dict(), os.path.join(self.outpath, self.image_name + "_model.pth"))
+
+    def clean(self):
+        self.iiter = 0
+        self.loss_min = None
+        self._out_best_dev = None
+        self.history = u.History(self.args.epochs)
+
+
+def main(argv=None):
+    args = parse_arguments(argv)
+    u.set_gpu(args.gpu if args.gpu is not None else -1)
+    u.set_seed(0)
+    outpath = os.path.join("./results/", args.outdir if args.outdir is not None else u.random_code())
+    os.makedirs(outpath, exist_ok=True)
+    print("Saving to %s" % outpath)
+    u.write_args(os.path.join(outpath, "args.txt"), args)
+    patches = extract_patches(args)
+    print("Processing %d patches" % len(patches))
+    T = Interpolator(args, outpath)
+    for i, patch in enumerate(patches):
+        std = T.load_data(patch)
+        print("\nThe data shape is %s, the std of coarse data is %.2e" % (str(patch["image"].shape), std))
+        if np.isclose(std, 0.0, atol=1e-12):
+            print("skipping...")
+            T.out_best = T.img * T.mask
+            T.elapsed = 0.0
+        else:
+            if T.net is None or not args.start_from_prev:
+                T.build_model(netpath=args.netdir[i]) if len(args.netdir) != 0 else T.build_model()
+            T.build_input()
+            T.optimize()
+        T.save_result()
+        T.clean()
+    print("Interpolation done! Saved to %s" % outpath)
+
+
+if __name__ == "__main__":
+    main()

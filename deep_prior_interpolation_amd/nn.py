@@ -1,0 +1,130 @@
+"""Leaf modules of the drop-in network tree.
+
+They subclass the torch parameter containers (so `state_dict` keys, default initialisation, RNG
+consumption order and `__class__.__name__` — which the reference's `init_weights` greps for 'Conv' /
+'BatchNorm', utils/torch.py:34-53 — are exactly torch's), but every `forward` runs the HIP kernels of
+libdpi_hip.so through `ops`; aten's conv / batch_norm / upsample are never called.
+"""
+import torch
+from torch import nn
+
+from . import ops
+
+
+class Conv3d(nn.Conv3d):
+    def __init__(self, in_f, out_f, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__(in_f, out_f, kernel_size, stride, padding=padding, bias=bias)
+        _check_conv(self, kernel_size, stride, padding)
+        self._s = int(stride)
+
+    def forward(self, x):
+        return ops.conv(x, self.weight, self.bias, self._s)
+
+
+class Conv2d(nn.Conv2d):
+    def __init__(self, in_f, out_f, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__(in_f, out_f, kernel_size, stride, padding=padding, bias=bias)
+        _check_conv(self, kernel_size, stride, padding)
+        self._s = int(stride)
+
+    def forward(self, x):
+        return ops.conv(x, self.weight, self.bias, self._s)
+
+
+def _check_conv(m, k, stride, padding):
+    if k not in (1, 3) or stride not in (1, 2) or padding != (k - 1) // 2 or (k == 1 and stride != 1):
+        raise NotImplementedError("HIP conv supports k in {1,3}, stride in {1,2}, 'same' zero padding "
+                                  "(got k=%r stride=%r pad=%r)" % (k, stride, padding))
+
+
+class _BatchNormMixin:
+    fused_slope = 1.0   # set by a parent container to fold the following LeakyReLU into the BN-apply pass
+
+    def forward(self, x):
+        # the reference never leaves training mode: always batch statistics + running update
+        return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var,
+                              self.num_batches_tracked, self.fused_slope)
+
+
+class BatchNorm3d(_BatchNormMixin, nn.BatchNorm3d):
+    pass
+
+
+class BatchNorm2d(_BatchNormMixin, nn.BatchNorm2d):
+    pass
+
+
+class LeakyReLU(nn.Module):
+    """LeakyReLU(slope); slope=0 gives ReLU.  (Out of place; the reference's inplace=True is a memory detail.)"""
+
+    def __init__(self, negative_slope=0.2):
+        super().__init__()
+        self.negative_slope = float(negative_slope)
+
+    def forward(self, x):
+        return ops.leaky_relu(x, self.negative_slope)
+
+    def extra_repr(self):
+        return "negative_slope=%g" % self.negative_slope
+
+
+class UnsupportedActivation(nn.Module):
+    def __init__(self, name):
+        super().__init__()
+        self.name = name
+
+    def forward(self, x):
+        raise NotImplementedError("activation %s has no HIP kernel yet (LeakyReLU / ReLU / none are supported)" % self.name)
+
+
+class Upsample(nn.Module):
+    def __init__(self, scale_factor=2, mode="nearest"):
+        super().__init__()
+        if scale_factor != 2:
+            raise NotImplementedError("only scale_factor=2")
+        self.scale_factor, self.mode = scale_factor, mode
+
+    def forward(self, x):
+        return ops.upsample2x(x, self.mode)
+
+    def extra_repr(self):
+        return "scale_factor=2, mode=%s" % self.mode
+
+
+class Dropout(nn.Module):
+    """Placeholder keeping the reference's module indices; p must be 0 (the reference default)."""
+
+    def __init__(self, p=0.0):
+        super().__init__()
+        self.p = float(p)
+
+    def forward(self, x):
+        if self.p != 0.0:
+            raise NotImplementedError("dropout > 0 is not on the HIP path")
+        return x
+
+
+class Seq(nn.Sequential):
+    """nn.Sequential whose `.add(m)` names the child str(len+1) — the naming rule the reference installs on
+    torch.nn.Module (architectures/base.py:69-73) and that its state_dict keys depend on."""
+
+    def add(self, module):
+        self.add_module(str(len(self) + 1), module)
+
+
+class Concat(nn.Module):
+    """Run every child on the same input, centre-crop to the smallest spatial size, cat on dim 1
+    (reference Concat / Concat3D, base.py:289-362)."""
+
+    def __init__(self, dim, *mods):
+        super().__init__()
+        assert dim == 1
+        self.dim = dim
+        for i, m in enumerate(mods):
+            self.add_module(str(i), m)
+
+    def forward(self, x):
+        return ops.concat_crop([m(x) for m in self._modules.values()])
+
+    def __len__(self):
+        return len(self._modules)

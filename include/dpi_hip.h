@@ -1,0 +1,168 @@
+/*
+ * dpi_hip.h — C ABI of libdpi_hip.so: the MI355X (gfx950) kernels behind the deep-prior
+ * interpolation hot path (MulResUnet3D / MulResUnet / Skip3D forward + backward, masked loss,
+ * metrics, Adam, overlap-add reassembly).
+ *
+ * The reference (polimi-ispl/deep_prior_interpolation) has NO native/FFI interface: its hot path
+ * sits behind `architectures.get_net(args, outchannel) -> torch.nn.Module`
+ * (architectures/__init__.py:10) and delegates all arithmetic to torch's aten kernels.  Each entry
+ * point below therefore cites the torch call site in the reference whose work it takes over; the
+ * Python binding a maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers owned by the caller (PyTorch caching allocator), fp32 unless
+ *    stated, batch N = 1 (the reference optimises one patch at a time, main.py:131-135), layout
+ *    channel-planar [C][D][H][W] with W contiguous.  2-D tensors use D = 1 and kd = 1.
+ *    A channel slice [c0:c1] of such a tensor is itself a valid tensor (zero-copy concat).
+ *  - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (graph-capturable:
+ *    no allocation, no synchronisation, no host read-back).
+ *  - Return value: 0 on success, negative DPI_E_* otherwise; dpi_last_error() gives the message of
+ *    the calling thread's last failure.  No exceptions cross the ABI.
+ *  - "chain": optional per-channel input transform applied while a tensor is LOADED, 5 floats per
+ *    channel {ps, pb, slope, qs, qb}:  T(x) = qs * act(ps*x + pb) + qb,  act(v) = v>0 ? v : slope*v.
+ *    It lets BatchNorm-apply + LeakyReLU be fused into the consumer instead of a separate pass.
+ *    NULL = identity.
+ *  - "stat partials": double[nblk][C][2] = per-block {sum, sum of squares}; reduced in fixed order by
+ *    dpi_bn_finalize (deterministic, double precision).
+ */
+#ifndef DPI_HIP_H
+#define DPI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPI_OK 0
+#define DPI_E_ARG (-1)      /* invalid argument / unsupported shape */
+#define DPI_E_LAUNCH (-2)   /* HIP launch or runtime error */
+#define DPI_E_WORKSPACE (-3)/* workspace too small */
+
+#define DPI_CHAIN_STRIDE 5
+
+const char* dpi_last_error(void);
+int dpi_version(void);
+/* Number of devices / properties as HIP sees them (no torch involved). */
+int dpi_device_info(int device, int* cus, int* lds_bytes, size_t* hbm_bytes, char* name, int name_len);
+
+/* ---------------------------------------------------------------- convolution ------------------
+ * Replaces nn.Conv3d / nn.Conv2d built at architectures/base.py:123,176 (k in {1,3}, stride in {1,2},
+ * zero padding (k-1)/2) and their autograd backward (aten convolution_backward).
+ * x: [Cin][D][H][W]   w: [Cout][Cin][kd][k][k]   y: [Cout][Do][Ho][Wo],  Xo = (X + 2*pad - k)/stride + 1.
+ * kd = k for 3-D, kd = 1 for 2-D (D must be 1).
+ */
+typedef struct {
+  int Cin, Cout;
+  int D, H, W;      /* input spatial size */
+  int k, kd;        /* kernel extent in H/W and in D */
+  int stride;       /* 1 or 2 (applies to D only when kd > 1) */
+} dpi_conv_desc;
+
+/* number of stat-partial blocks dpi_conv_fwd writes for this problem (0 if desc invalid) */
+int dpi_conv_fwd_stat_blocks(const dpi_conv_desc* d);
+/* y = conv(T(x), w) + bias.  bias may be NULL.  stat_partials (may be NULL): double[nblk][Cout][2]. */
+int dpi_conv_fwd(const dpi_conv_desc* d, const float* x, const float* x_chain, const float* w,
+                 const float* bias, float* y, double* stat_partials, void* stream);
+/* dx (+)= conv_transpose(dy, w):  dx [Cin][D][H][W], dy [Cout][Do][Ho][Wo].  accumulate != 0 adds. */
+int dpi_conv_bwd_data(const dpi_conv_desc* d, const float* dy, const float* w, float* dx,
+                      int accumulate, void* stream);
+/* dw[Cout][Cin][kd][k][k] = sum_p dy[co][p] * T(x)[ci][p*stride + tap - pad].
+ * workspace: float[dpi_conv_bwd_weight_ws_floats(d)].  */
+size_t dpi_conv_bwd_weight_ws_floats(const dpi_conv_desc* d);
+int dpi_conv_bwd_weight(const dpi_conv_desc* d, const float* x, const float* x_chain, const float* dy,
+                        float* dw, float* ws, size_t ws_floats, void* stream);
+
+/* ---------------------------------------------------------------- BatchNorm / activations -------
+ * Replaces nn.BatchNorm3d/2d in training mode (base.py:164,214; mulresunet.py:80-81,104,225) and
+ * LeakyReLU(0.2) (base.py:102), plus their backward.
+ */
+int dpi_stat_blocks(int C, size_t V);
+/* partials[nblk][C][2] of T(x) over the V voxels of each channel */
+int dpi_channel_stats(const float* x, const float* chain, int C, size_t V, double* partials, void* stream);
+/* Reduce partials -> mean, invstd (biased var, eps); update running stats (momentum, unbiased var);
+ * write chain_out[c] = {gamma*invstd, beta - mean*gamma*invstd, slope, 1, 0}  (i.e. BN-apply followed
+ * by act with `slope`; slope = 1 means no activation).  running_* / nbt / chain_out may be NULL.
+ * mean_invstd: float[2][C]. */
+int dpi_bn_finalize(const double* partials, int nblk, int C, size_t count, const float* gamma,
+                    const float* beta, float eps, float momentum, float slope, float* running_mean,
+                    float* running_var, int64_t* num_batches_tracked, float* mean_invstd,
+                    float* chain_out, void* stream);
+/* y = T(x) elementwise */
+int dpi_chain_apply(const float* x, const float* chain, int C, size_t V, float* y, void* stream);
+/* BatchNorm backward, phase 1: partials[nblk][C][2] = {sum dy, sum dy*xhat}, xhat = (x-mean)*invstd */
+int dpi_bn_bwd_reduce(const float* dy, const float* x, const float* mean_invstd, int C, size_t V,
+                      double* partials, void* stream);
+/* phase 2: dx = gamma*invstd*(dy - sum_dy/V - xhat*sum_dyxhat/V); dgamma = sum_dyxhat; dbeta = sum_dy */
+int dpi_bn_bwd_apply(const float* dy, const float* x, const float* mean_invstd, const float* gamma,
+                     const double* partials, int nblk, int C, size_t V, float* dx, float* dgamma,
+                     float* dbeta, void* stream);
+/* dx = dy * act'(x) with act(v) = v>0 ? v : slope*v  (x = the activation INPUT or OUTPUT: same sign) */
+int dpi_lrelu_bwd(const float* dy, const float* x, float slope, size_t n, float* dx, void* stream);
+/* y = a + b */
+int dpi_add(const float* a, const float* b, size_t n, float* y, void* stream);
+/* per-channel sum: out[c] = sum_v x[c][v]   (bias gradients) ; ws: double[dpi_stat_blocks*C*2] */
+int dpi_channel_sum(const float* x, int C, size_t V, double* ws, float* out, void* stream);
+
+/* ---------------------------------------------------------------- up-sampling / concat ----------
+ * Replaces nn.Upsample(scale_factor=2, mode=nearest|bilinear|trilinear, align_corners=False)
+ * (mulresunet.py:168,242; skip.py:128,231) fused with the centre-crop of Concat/Concat3D
+ * (base.py:297-319,333-359): the output may be cropped to (Do,Ho,Wo) <= 2*(D,H,W), offset 0.
+ * 2-D: D = Do = 1 (no scaling along D when D == Do == 1).
+ */
+int dpi_upsample2x_fwd(const float* x, const float* chain, int C, int D, int H, int W, int Do, int Ho,
+                       int Wo, int linear, float* y, void* stream);
+int dpi_upsample2x_bwd(const float* dy, int C, int D, int H, int W, int Do, int Ho, int Wo, int linear,
+                       float* dx, void* stream);
+/* centre-crop copy [C][D][H][W] -> [C][Do][Ho][Wo] starting at (od,oh,ow); and its adjoint (zero-fill) */
+int dpi_crop_copy(const float* x, int C, int D, int H, int W, int od, int oh, int ow, int Do, int Ho,
+                  int Wo, float* y, void* stream);
+int dpi_crop_copy_bwd(const float* dy, int C, int D, int H, int W, int od, int oh, int ow, int Do,
+                      int Ho, int Wo, float* dx, void* stream);
+
+/* ---------------------------------------------------------------- loss + metrics ----------------
+ * Replaces main.py:161-167: loss = mean(|out*m - img*m|) (kind 0, L1) or mean((.)^2) (kind 1, MSE)
+ * over all n elements; dout = dloss/dout * grad_scale; plus the sums for snr/pcorr
+ * (utils/metrics.py:15,32-36).  ws: double[dpi_loss_ws_doubles(n)].
+ * result (device, double[8]): {loss, snr_dB, pcorr, sum_t2, sum_(t-o)^2, sum_o, sum_t, reserved}.
+ */
+size_t dpi_loss_ws_doubles(size_t n);
+int dpi_masked_loss(const float* out, const float* img, const float* mask, size_t n, int kind,
+                    float grad_scale, float* dout, double* ws, double* result, void* stream);
+
+/* ---------------------------------------------------------------- optimiser ---------------------
+ * Replaces torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8).step() (main.py:200,213) for a list of
+ * tensors in ONE launch.  ptrs: device array of {p, g, m, v} pointers per tensor; sizes: element counts;
+ * step_lr (device, float[2]): {step count as float (already incremented), lr}.  `active` (device int,
+ * may be NULL): when *active == 0 the update is skipped (device-side early stop).
+ */
+typedef struct { float* p; const float* g; float* m; float* v; } dpi_adam_tensor;
+int dpi_adam_multi(const dpi_adam_tensor* tensors, const int64_t* sizes, int ntensors,
+                   const float* step_lr, float beta1, float beta2, float eps, const int* active,
+                   void* stream);
+
+/* ---------------------------------------------------------------- input perturbation ------------
+ * Replaces main.py:148-150: out = z + std * N(0,1), Philox4x32-10 + Box-Muller, counter = element index,
+ * key = (seed, *step_ptr) so that every replay of a captured graph draws fresh noise.
+ * step_ptr (device, uint64) may be NULL (then step = 0).
+ */
+int dpi_noise_add(const float* z, size_t n, float std, uint64_t seed, const uint64_t* step_ptr,
+                  float* out, void* stream);
+int dpi_fill_normal(float* out, size_t n, float mean, float std, uint64_t seed, uint64_t stream_id,
+                    void* stream);
+
+/* ---------------------------------------------------------------- patch reassembly --------------
+ * Replaces PatchExtractor.reconstruct (utils/patch_extractor.py:395-428): overlap-add of one patch
+ * (pd,ph,pw) at origin (od,oh,ow) into acc[D][H][W]; dpi_overlap_normalize divides by the analytic hit
+ * count of the regular window grid and by `gain` (data.py:116).
+ */
+int dpi_overlap_add(const float* patch, int pd, int ph, int pw, int od, int oh, int ow, float* acc,
+                    int D, int H, int W, void* stream);
+int dpi_overlap_normalize(float* acc, int D, int H, int W, int pd, int ph, int pw, int sd, int sh,
+                          int sw, float gain, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPI_HIP_H */

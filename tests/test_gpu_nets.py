@@ -1,0 +1,139 @@
+"""GPU parity of blocks, whole networks and the optimisation loop against the golden vectors recorded
+from the reference (tiny nets, reference's own per-iteration inputs) — everything through the HIP path."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import jstr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def G(a, grad=False):
+    t = torch.from_numpy(np.array(a, dtype=np.float32)).to(DEV)
+    return t.requires_grad_(True) if grad else t
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.linalg.norm((a - b).ravel()) / (np.linalg.norm(b.ravel()) + 1e-30))
+
+
+def _load_sd(module, state):
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in state.items()}
+    module.load_state_dict(sd)
+    return module.to(DEV)
+
+
+@pytest.mark.parametrize("name", ["block3d", "block3d_u16", "respath3d", "block2d", "respath2d"])
+def test_blocks_golden(golden, name):
+    from deep_prior_interpolation_amd.architectures.mulresunet import MultiResBlock, ResPath
+    g = golden("blocks")[name]
+    mk = {"block3d": lambda: MultiResBlock(3, 8, 5), "block3d_u16": lambda: MultiResBlock(3, 16, 11),
+          "respath3d": lambda: ResPath(3, 7, 4), "block2d": lambda: MultiResBlock(2, 8, 5),
+          "respath2d": lambda: ResPath(2, 7, 4)}[name]
+    m = _load_sd(mk(), g["state"])
+    x = G(g["x"], True)
+    y = m(x)
+    assert rel(y, g["y"]) < 2e-5
+    y.backward(G(g["dy"]))
+    assert rel(x.grad, g["dx"]) < 1e-4
+    for k, p in m.named_parameters():
+        ref = g["grads"][k]
+        if np.linalg.norm(ref) < 1e-3:                     # analytically-zero gradients (feed a BatchNorm)
+            assert float(p.grad.abs().max()) < 1e-3, k
+        else:
+            assert rel(p.grad, ref) < 3e-4, k
+    sd = m.state_dict()
+    for k, v in g["state_after"].items():
+        if "running" in k:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), v, rtol=1e-5, atol=1e-6, err_msg=k)
+        if "num_batches" in k:
+            assert int(sd[k]) == int(v)
+
+
+NETS = ["net_mulresunet3d_tiny_trilinear_mae", "net_mulresunet3d_tiny_nearest_mse", "net_mulresunet3d_tiny_odd",
+        "net_skip3d_tiny", "net_mulresunet2d_tiny", "net_mulresunet25d_tiny"]
+
+
+def _interpolator(g, epochs):
+    from deep_prior_interpolation_amd.main import Interpolator
+    a = Namespace(**jstr(g["args"]))
+    a.epochs = epochs
+    a.gpu = 0
+    T = Interpolator(a, "/tmp")
+    T.load_data({"image": g["image"], "mask": g["mask"], "name": "0"})
+    T.build_model()
+    _load_sd(T.net, g["init_state"])
+    T.input_ = G(g["z"])
+    return T, a
+
+
+@pytest.mark.parametrize("name", NETS)
+def test_net_iteration0(golden, name):
+    g = golden(name)
+    T, a = _interpolator(g, 1)
+    assert abs(T.load_data({"image": g["image"], "mask": g["mask"], "name": "0"}) - float(g["std"])) < 1e-5 * float(g["std"])
+    T.optimize(net_inputs=[G(g["net_inputs"][0])], verbose=False)
+    assert abs(T.history.loss[0] - g["loss"][0]) <= 1e-5 * abs(g["loss"][0])
+    assert abs(T.history.snr[0] - g["snr"][0]) <= 1e-3
+    assert abs(T.history.pcorr[0] - g["pcorr"][0]) <= 1e-4
+
+
+@pytest.mark.parametrize("name", NETS)
+def test_net_trajectory(golden, name):
+    g = golden(name)
+    K = len(g["loss"])
+    T, a = _interpolator(g, K)
+    T.optimize(net_inputs=[G(x) for x in g["net_inputs"]], verbose=False)
+    np.testing.assert_allclose(T.history.loss, g["loss"], rtol=5e-3)
+    np.testing.assert_allclose(T.history.snr, g["snr"], atol=0.1)
+    np.testing.assert_allclose(T.history.pcorr, g["pcorr"], atol=1e-2)
+    assert np.argmin(T.history.loss) == np.argmin(g["loss"])
+    assert T.out_best.shape == g["out_best"].shape
+    assert rel(T.out_best, g["out_best"]) < 1e-2
+    fin = T.net.state_dict()
+    for k, v in g["final_state"].items():
+        if k.endswith("weight") and v.ndim > 1:
+            assert rel(fin[k], v) < 5e-2, k
+
+
+def test_full_size_net_one_step_vs_oracle():
+    """Full default MulResUnet3D (5.9 M parameters) on a 32^3 patch: iteration-0 loss/metrics and all weight
+    gradients against the CPU oracle (same theta, same input)."""
+    from deep_prior_interpolation_amd import ops, utils as u
+    from deep_prior_interpolation_amd.architectures import get_net
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    from oracle import dpi_oracle as O
+    a = parse_arguments(["--imgdir", "x", "--datadim", "3d", "--upsample", "linear"])
+    u.set_seed(0)
+    net = get_net(a, 1)
+    u.init_weights(net, a.inittype, a.initgain)
+    init = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    gen = torch.Generator().manual_seed(1)
+    x = 0.1 * torch.randn((1, 64, 32, 32, 32), generator=gen)
+    img = torch.randn((1, 1, 32, 32, 32), generator=gen)
+    mask = (torch.rand((1, 1, 1, 32, 32), generator=gen) > 0.5).float().expand(1, 1, 32, 32, 32).contiguous()
+    S = O.NetState(init)
+    cfg = {"ndim": 3, "filters": a.filters, "skip": a.skip, "upsample": "trilinear"}
+    out_r = O.net_forward(S, x, cfg)
+    loss_r = O.masked_loss(out_r, img, mask, "mae")
+    loss_r.backward()
+    net = net.to(DEV)
+    out = net(x.to(DEV))
+    loss, met = ops.masked_loss(out, img.to(DEV), mask.to(DEV), "mae")
+    loss.backward()
+    assert rel(out, out_r.detach().numpy()) < 1e-4
+    assert abs(loss.item() - loss_r.item()) < 1e-5 * abs(loss_r.item())
+    assert abs(met[1].item() - O.snr(out_r.detach(), img).item()) < 1e-3
+    worst = 0.0
+    for k, p in net.named_parameters():
+        gr = S.P[k].grad.numpy()
+        if p.ndim > 1:                                   # conv weights carry the real gradient signal
+            worst = max(worst, rel(p.grad, gr))
+    assert worst < 2e-3, worst

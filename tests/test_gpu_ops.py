@@ -1,0 +1,302 @@
+"""GPU parity of the leaf ops: HIP kernels (through the C ABI / ctypes / autograd wrappers) against
+ (1) the golden vectors recorded from the reference, (2) the CPU oracle on seeded random inputs,
+ (3) size-independent properties (adjoint dot-tests, linearity) at BASELINE sizes.
+Tolerances: fp32; forward rtol 1e-5..1e-4, gradients norm-wise 2e-4 (different summation order)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dpi_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def G(a, grad=False):
+    t = torch.from_numpy(np.array(a, dtype=np.float32)).to(DEV)
+    return t.requires_grad_(True) if grad else t
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(b) else np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.linalg.norm((a - b).ravel()) / (np.linalg.norm(b.ravel()) + 1e-30))
+
+
+def close(a, b, rtol, atol, what=""):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from deep_prior_interpolation_amd import ops as _ops
+    return _ops
+
+
+CONVS = ["conv3d_k3s1", "conv3d_k3s1_wide", "conv3d_k3s2_odd", "conv3d_k3s2_even", "conv3d_k1",
+         "conv2d_k3s1", "conv2d_k3s2", "conv2d_k1"]
+
+
+@pytest.mark.parametrize("name", CONVS)
+def test_conv_golden(golden, ops, name):
+    g = golden("ops")[name]
+    stride = 2 if "s2" in name else 1
+    x, w, b = G(g["x"], True), G(g["state"]["0.weight"], True), G(g["state"]["0.bias"], True)
+    y = ops.conv(x, w, b, stride)
+    close(y, g["y"], 1e-5, 2e-5, "y")
+    y.backward(G(g["dy"]))
+    close(x.grad, g["dx"], 1e-5, 2e-5, "dx")
+    close(w.grad, g["grads"]["0.weight"], 1e-5, 5e-5, "dw")
+    close(b.grad, g["grads"]["0.bias"], 1e-5, 5e-5, "db")
+
+
+CONV_RANDOM = [
+    # Cin, Cout, (D,H,W), k, stride
+    (64, 4, (16, 20, 36), 3, 1), (4, 8, (9, 17, 33), 3, 1), (8, 13, (8, 8, 32), 3, 1), (25, 16, (12, 9, 40), 3, 1),
+    (67, 4, (6, 10, 34), 3, 1), (25, 1, (8, 16, 32), 3, 1), (35, 71, (8, 8, 8), 3, 1), (71, 142, (4, 4, 4), 3, 1),
+    (25, 25, (16, 16, 32), 3, 2), (51, 51, (9, 11, 13), 3, 2), (3, 5, (2, 2, 2), 3, 2), (5, 3, (1, 1, 1), 3, 1),
+    (64, 25, (8, 16, 32), 1, 1), (137, 51, (5, 7, 9), 1, 1), (554, 35, (4, 4, 4), 1, 1), (25, 16, (8, 8, 33), 1, 1),
+]
+
+
+@pytest.mark.parametrize("cin,cout,shape,k,stride", CONV_RANDOM)
+def test_conv_vs_oracle(ops, cin, cout, shape, k, stride):
+    gen = torch.Generator().manual_seed(cin * 1000 + cout)
+    x = torch.randn((1, cin) + shape, generator=gen)
+    w = torch.randn((cout, cin, k, k, k), generator=gen) * (1.0 / np.sqrt(cin * k ** 3))
+    b = torch.randn(cout, generator=gen)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = O.conv_nd(xr, wr, br, stride)
+    dy = torch.randn(yr.shape, generator=gen)
+    yr.backward(dy)
+    xg, wg, bg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = ops.conv(xg, wg, bg, stride)
+    assert rel(y, yr) < 2e-6
+    y.backward(dy.to(DEV))
+    assert rel(xg.grad, xr.grad) < 2e-6
+    assert rel(wg.grad, wr.grad) < 5e-6
+    assert rel(bg.grad, br.grad) < 5e-6
+
+
+@pytest.mark.parametrize("cin,cout,shape,k,stride", [(5, 7, (1, 37, 41), 3, 1), (6, 6, (1, 33, 30), 3, 2), (9, 4, (1, 20, 24), 1, 1)])
+def test_conv2d_vs_oracle(ops, cin, cout, shape, k, stride):
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn((1, cin) + shape[1:], generator=gen)
+    w = torch.randn((cout, cin, k, k), generator=gen) * 0.2
+    b = torch.randn(cout, generator=gen)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = O.conv_nd(xr, wr, br, stride)
+    dy = torch.randn(yr.shape, generator=gen)
+    yr.backward(dy)
+    xg, wg, bg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = ops.conv(xg, wg, bg, stride)
+    assert rel(y, yr) < 2e-6
+    y.backward(dy.to(DEV))
+    assert rel(xg.grad, xr.grad) < 2e-6 and rel(wg.grad, wr.grad) < 5e-6 and rel(bg.grad, br.grad) < 5e-6
+
+
+def test_conv_fused_chain_and_stats(ops):
+    """conv(T(x)) with the BN-apply+LeakyReLU chain fused into the load, and the {sum, sum^2} epilogue."""
+    import ctypes as C
+    from deep_prior_interpolation_amd import _lib
+    gen = torch.Generator().manual_seed(3)
+    cin, cout, shape = 13, 9, (7, 12, 37)
+    x = torch.randn((1, cin) + shape, generator=gen)
+    chain = torch.stack([torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen), torch.full((cin,), 0.2),
+                         torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen)], dim=1).contiguous()
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen) * 0.1
+    b = torch.randn(cout, generator=gen)
+    bc = lambda v: v.reshape(1, -1, 1, 1, 1)
+    tx = bc(chain[:, 3]) * O.activation("LeakyReLU", bc(chain[:, 0]) * x + bc(chain[:, 1])) + bc(chain[:, 4])
+    yr = O.conv_nd(tx, w, b, 1)
+    L = _lib.load()
+    xg, wg, bg, cg = x.to(DEV), w.to(DEV), b.to(DEV), chain.to(DEV)
+    d = ops.make_desc(xg, wg, 1)
+    nblk = L.dpi_conv_fwd_stat_blocks(C.byref(d))
+    part = torch.zeros(nblk * cout * 2, dtype=torch.float64, device=DEV)
+    y = torch.empty(yr.shape, device=DEV)
+    ops.raw_conv_fwd(d, xg, cg, wg, bg, y, part)
+    assert rel(y, yr) < 2e-6
+    p = part.view(nblk, cout, 2).sum(0).cpu()
+    yr64 = yr.double()
+    np.testing.assert_allclose(p[:, 0].numpy(), yr64.sum((0, 2, 3, 4)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(p[:, 1].numpy(), (yr64 ** 2).sum((0, 2, 3, 4)).numpy(), rtol=1e-5)
+    # backward-weight with the same chain on x
+    dy = torch.randn(yr.shape, generator=gen)
+    txr = tx.clone().requires_grad_(False)
+    wr = w.clone().requires_grad_(True)
+    O.conv_nd(txr, wr, None, 1).backward(dy)
+    dw = torch.empty_like(wg)
+    ops.raw_conv_bwd_weight(d, xg, cg, dy.to(DEV), dw)
+    assert rel(dw, wr.grad) < 5e-6
+
+
+@pytest.mark.parametrize("name", ["bn3d", "bn2d"])
+def test_bn_golden(golden, ops, name):
+    g = golden("ops")[name]
+    st = g["state"]
+    x, ga, be = G(g["x"], True), G(st["weight"], True), G(st["bias"], True)
+    rm, rv = G(st["running_mean"]), G(st["running_var"])
+    nbt = torch.tensor(int(st["num_batches_tracked"]), device=DEV)
+    y = ops.batch_norm(x, ga, be, rm, rv, nbt)
+    close(y, g["y"], 1e-5, 1e-5)
+    y.backward(G(g["dy"]))
+    close(x.grad, g["dx"], 1e-4, 1e-5)
+    close(ga.grad, g["grads"]["weight"], 1e-5, 2e-5)
+    close(be.grad, g["grads"]["bias"], 1e-5, 2e-5)
+    close(rm, g["state_after"]["running_mean"], 1e-6, 1e-7)
+    close(rv, g["state_after"]["running_var"], 1e-6, 1e-7)
+    assert int(nbt) == int(g["state_after"]["num_batches_tracked"])
+
+
+def test_bn_large_offset(ops):
+    """Statistics stay accurate when |mean| >> std (double-precision two-stage reduction)."""
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn((1, 3, 16, 32, 32), generator=gen) * 0.01 + torch.tensor([100.0, -50.0, 0.0]).reshape(1, 3, 1, 1, 1)
+    ga, be = torch.ones(3), torch.zeros(3)
+    yr = O.batch_norm_train(x.double(), ga.double(), be.double())
+    y = ops.batch_norm(x.to(DEV), ga.to(DEV), be.to(DEV))
+    assert rel(y, yr.float()) < 2e-3      # fp32 input quantisation of 100 +- 0.01 dominates
+    assert abs(float(y.mean())) < 1e-3
+
+
+def test_lrelu_upsample_concat_golden(golden, ops):
+    g = golden("ops")["lrelu"]
+    x = G(g["x"], True)
+    y = ops.leaky_relu(x, 0.2)
+    close(y, g["y"], 0, 0)
+    y.backward(G(g["dy"]))
+    close(x.grad, g["dx"], 0, 0)
+    for name, mode in [("up3d_nearest", "nearest"), ("up3d_trilinear", "trilinear"), ("up3d_trilinear_1", "trilinear"),
+                       ("up2d_nearest", "nearest"), ("up2d_bilinear", "bilinear")]:
+        g = golden("ops")[name]
+        x = G(g["x"], True)
+        y = ops.upsample2x(x, mode)
+        close(y, g["y"], 1e-6, 1e-6, name)
+        y.backward(G(g["dy"]))
+        close(x.grad, g["dx"], 1e-5, 1e-6, name)
+    for name in ("concat3d_crop", "concat2d_crop"):
+        g = golden("ops")[name]
+        x = G(g["x"], True)
+        deep = ops.upsample2x(ops.conv(x, G(g["state"]["1.0.0.weight"]), G(g["state"]["1.0.0.bias"]), 2), "nearest")
+        y = ops.concat_crop([x, deep])
+        close(y, g["y"], 1e-5, 1e-5, name)
+        y.backward(G(g["dy"]))
+        close(x.grad, g["dx"], 1e-5, 2e-5, name)
+
+
+def test_upsample_crop_vs_oracle(ops):
+    """Up-sampling fused with the Concat centre-crop (odd skip sizes): out = up(x)[:Do,:Ho,:Wo]."""
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn((1, 3, 4, 5, 6), generator=gen)
+    for mode in ("nearest", "trilinear"):
+        xr = x.clone().requires_grad_(True)
+        yr = O.upsample2x(xr, mode)[:, :, :7, :9, :12]
+        dy = torch.randn(yr.shape, generator=gen)
+        yr.backward(dy)
+        xg = x.to(DEV).requires_grad_(True)
+        y = ops.upsample2x(xg, mode, (7, 9, 12))
+        assert rel(y, yr) < 1e-6
+        y.backward(dy.to(DEV))
+        assert rel(xg.grad, xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["mae", "mse"])
+def test_masked_loss_metrics(ops, kind):
+    gen = torch.Generator().manual_seed(11)
+    shape = (1, 1, 20, 33, 31)
+    out = torch.randn(shape, generator=gen)
+    img = out + 0.3 * torch.randn(shape, generator=gen) + 0.1
+    mask = (torch.rand((1, 1, 1, 33, 31), generator=gen) > 0.5).float().expand(shape).contiguous()
+    o_r = out.clone().requires_grad_(True)
+    lr_ = O.masked_loss(o_r, img, mask, kind)
+    lr_.backward()
+    og = out.to(DEV).requires_grad_(True)
+    loss, met = ops.masked_loss(og, img.to(DEV), mask.to(DEV), kind)
+    loss.backward()
+    assert abs(loss.item() - lr_.item()) < 2e-6 * abs(lr_.item())
+    assert rel(og.grad, o_r.grad) < 1e-6
+    m = met.cpu().numpy()
+    assert abs(m[1] - O.snr(out.double(), img.double()).item()) < 1e-6
+    assert abs(m[2] - O.pcorr(out.double(), img.double()).item()) < 1e-8
+
+
+def test_adam_golden(golden):
+    from deep_prior_interpolation_amd.optim import FusedAdam
+    a = golden("host")["adam"]
+    p = torch.nn.Parameter(G(a["p0"]))
+    q = torch.nn.Parameter(torch.zeros(5, device=DEV))     # a second tensor in the same launch
+    opt = FusedAdam([p, q], lr=1e-3)
+    for k in range(5):
+        p.grad = G(a["grads"][k])
+        q.grad = torch.ones(5, device=DEV) * (k + 1)
+        opt.step()
+        np.testing.assert_allclose(p.detach().cpu().numpy(), a["traj"][k], rtol=5e-6, atol=2e-9)
+    np.testing.assert_allclose(opt._m[0].cpu().numpy(), a["m"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(opt._v[0].cpu().numpy(), a["v"], rtol=1e-6, atol=1e-20)
+    assert torch.all(q < 0)
+
+
+def test_noise_statistics():
+    from deep_prior_interpolation_amd import _lib
+    L = _lib.load()
+    n = 1 << 22
+    z = torch.zeros(n, device=DEV)
+    out = torch.empty(n, device=DEV)
+    step = torch.tensor([1], dtype=torch.int64, device=DEV)
+    _lib.check(L.dpi_noise_add(_lib.ptr(z), n, 0.03, 1234, _lib.ptr(step), _lib.ptr(out), _lib.stream()))
+    a = out.double().cpu().numpy()
+    assert abs(a.mean()) < 1e-4 and abs(a.std() - 0.03) < 1e-4
+    k = ((a / 0.03) ** 4).mean()
+    assert abs(k - 3.0) < 0.05                      # normal kurtosis
+    out2 = torch.empty(n, device=DEV)
+    step += 1
+    _lib.check(L.dpi_noise_add(_lib.ptr(z), n, 0.03, 1234, _lib.ptr(step), _lib.ptr(out2), _lib.stream()))
+    assert abs(np.corrcoef(a, out2.double().cpu().numpy())[0, 1]) < 5e-3   # fresh draw per step
+    out3 = torch.empty(n, device=DEV)
+    _lib.check(L.dpi_noise_add(_lib.ptr(z), n, 0.03, 1234, _lib.ptr(step), _lib.ptr(out3), _lib.stream()))
+    assert torch.equal(out2, out3)                   # deterministic given (seed, step)
+
+
+def test_overlap_add_vs_oracle():
+    from deep_prior_interpolation_amd import _lib
+    from deep_prior_interpolation_amd.utils import window_origins
+    L = _lib.load()
+    rng = np.random.RandomState(0)
+    shape, dim, stride = (20, 18, 22), (8, 6, 10), (4, 4, 6)
+    grid = O.patch_grid(shape, dim, stride)
+    pa = rng.randn(*(grid + dim)).astype(np.float32)
+    ref = O.reconstruct_nd(pa.astype(np.float64), dim, stride) / 40.0
+    cs = ref.shape
+    acc = torch.zeros(cs, device=DEV)
+    flat = pa.reshape((-1,) + dim)
+    for p, org in zip(flat, window_origins(shape, dim, stride)):
+        t = torch.from_numpy(p).to(DEV)
+        _lib.check(L.dpi_overlap_add(_lib.ptr(t), *dim, *[int(o) for o in org], _lib.ptr(acc), *cs, _lib.stream()))
+    _lib.check(L.dpi_overlap_normalize(_lib.ptr(acc), *cs, *dim, *stride, 40.0, _lib.stream()))
+    np.testing.assert_allclose(acc.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+
+
+# ---- size-independent properties at BASELINE sizes (configs[2]: 64^3 patch, 64-channel input) -------------------
+def test_conv_adjoint_and_linearity_at_full_size(ops):
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    for cin, cout, shape, k, s in [(64, 4, (64, 64, 64), 3, 1), (25, 16, (64, 64, 64), 3, 1), (25, 25, (64, 64, 64), 3, 2),
+                                   (67, 25, (64, 64, 64), 1, 1)]:
+        x = torch.randn((1, cin) + shape, device=DEV, generator=gen)
+        x2 = torch.randn((1, cin) + shape, device=DEV, generator=gen)
+        w = (torch.randn((cout, cin, k, k, k), device=DEV, generator=gen) / np.sqrt(cin * k ** 3)).requires_grad_(True)
+        xg = x.clone().requires_grad_(True)
+        y = ops.conv(xg, w, None, s)
+        dy = torch.randn(y.shape, device=DEV, generator=gen)
+        y.backward(dy)
+        lhs = float((y.double() * dy.double()).sum())
+        assert abs(lhs - float((x.double() * xg.grad.double()).sum())) < 1e-5 * abs(lhs) + 1e-3     # <Ax,y> = <x,A^T y>
+        assert abs(lhs - float((w.double() * w.grad.double()).sum())) < 1e-5 * abs(lhs) + 1e-3     # bilinear in W
+        y2 = ops.conv(x2, w.detach(), None, s)
+        y12 = ops.conv(x + x2, w.detach(), None, s)
+        assert rel(y12, y.detach() + y2) < 1e-6

@@ -1,0 +1,230 @@
+"""CPU-side tests: the drop-in host surface against the golden vectors recorded from the reference, the C-ABI
+library's exported symbols, and the 'no CPU fallback' contract.  No GPU needed."""
+import json
+import os
+import re
+import subprocess
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, jstr
+
+from deep_prior_interpolation_amd import utils as u
+from deep_prior_interpolation_amd import data as D
+from deep_prior_interpolation_amd.architectures import get_net
+from deep_prior_interpolation_amd.parameter import parse_arguments, net_args_are_same
+
+
+# ---------------------------------------------------------------- C ABI -------------------------------------------
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "dpi_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dpi_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from deep_prior_interpolation_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    syms = _header_symbols()
+    assert len(syms) >= 25
+    assert sorted(_lib.SIGNATURES.keys()) == syms            # the ctypes table covers the header, nothing more
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r"\bT (dpi_[a-z0-9_]+)", out))
+    assert set(syms) <= exported, set(syms) - exported
+    lib = _lib.load()                                         # loads without a GPU; no compute call made
+    assert lib.dpi_version() >= 100
+    assert lib.dpi_stat_blocks(4, 1 << 20) > 0
+
+
+def test_no_cpu_fallback():
+    from deep_prior_interpolation_amd import ops, _lib
+    x = torch.randn(1, 2, 4, 4, 4)
+    w = torch.randn(3, 2, 3, 3, 3)
+    with pytest.raises(_lib.DpiError):
+        ops.conv(x, w, None, 1)
+    with pytest.raises(_lib.DpiError):
+        ops.batch_norm(x, torch.ones(2), torch.zeros(2))
+    a = parse_arguments(["--imgdir", "x", "--datadim", "3d", "--filters", "4", "8", "--skip", "4", "--inputdepth", "2"])
+    with pytest.raises(_lib.DpiError):
+        get_net(a, 1)(x)
+
+
+# ---------------------------------------------------------------- networks ----------------------------------------
+def _args(argv, net=None):
+    a = parse_arguments(argv)
+    if net:
+        a.net = net
+    return a
+
+
+STRUCT = {
+    "mulresunet3d_default": (["--imgdir", "x", "--datadim", "3d"], 1, None),
+    "mulresunet2d_default": (["--imgdir", "x", "--datadim", "2d"], 1, None),
+    "mulresunet25d_c8": (["--imgdir", "x", "--datadim", "2.5d", "--imgchannel", "8"], 8, None),
+    "skip3d_a12": (["--imgdir", "x", "--datadim", "3d", "--filters", "16", "32", "64", "128", "128", "--skip", "4", "4", "4", "4", "4"], 1, "skip"),
+    "mulresunet3d_noskip": (["--imgdir", "x", "--datadim", "3d", "--filters", "4", "8", "16", "--skip", "0", "4"], 1, None),
+}
+
+
+@pytest.mark.parametrize("tag", list(STRUCT))
+def test_state_dict_keys_and_param_counts(golden, tag):
+    argv, outch, net = STRUCT[tag]
+    n = get_net(_args(argv, net), outch)
+    keys = [[k, list(v.shape)] for k, v in n.state_dict().items()]
+    assert keys == jstr(golden("structure")[tag]["keys"])           # same names, shapes AND order
+    assert sum(p.numel() for p in n.parameters()) == int(golden("structure")[tag]["num_params"])
+
+
+def test_param_counts_survey():
+    assert sum(p.numel() for p in get_net(_args(STRUCT["mulresunet3d_default"][0]), 1).parameters()) == 5923614
+    assert sum(p.numel() for p in get_net(_args(STRUCT["mulresunet2d_default"][0]), 1).parameters()) == 2186704
+
+
+@pytest.mark.parametrize("name", ["net_mulresunet3d_tiny_trilinear_mae", "net_skip3d_tiny", "net_mulresunet2d_tiny",
+                                  "net_mulresunet25d_tiny", "net_mulresunet3d_tiny_odd"])
+def test_same_seed_init_is_bit_identical(golden, name):
+    """set_seed(0) + get_net + init_weights reproduces the reference's initial state_dict exactly
+    (same construction order => same RNG consumption)."""
+    g = golden(name)
+    ns = Namespace(**jstr(g["args"]))
+    u.set_seed(0)
+    oc = g["image"].shape[-1] if ns.imgchannel is None else ns.imgchannel
+    net = get_net(ns, oc)
+    u.init_weights(net, ns.inittype, ns.initgain)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(g["init_state"].keys())
+    for k, v in g["init_state"].items():
+        assert np.array_equal(sd[k].numpy(), v), k
+
+
+def test_out_of_scope_nets_are_loud():
+    for net in ("unet", "attmultiunet", "part"):
+        with pytest.raises(NotImplementedError):
+            get_net(_args(["--imgdir", "x", "--datadim", "2d", "--net", net]), 1)
+
+
+# ---------------------------------------------------------------- parameter ---------------------------------------
+def test_parameter_defaults_and_postprocessing():
+    a = parse_arguments(["--imgdir", "d"])
+    assert (a.gain, a.datadim, a.net, a.filters, a.skip, a.inputdepth) == (2e3, "2d", "multiunet", [16, 32, 64, 128, 256], [16, 32, 64, 128], 64)
+    assert (a.upsample, a.inittype, a.initgain, a.loss, a.epochs, a.lr) == ("nearest", "xavier", 0.02, "mae", 2001, 1e-3)
+    assert a.param_noise is True and a.reg_noise_std == 0.03 and a.noise_std == 0.1 and a.noise_dist == "n"
+    assert a.patch_shape == [-1, -1] and a.patch_stride == [-1, -1] and a.earlystop_patience == 2001 and a.netdir == []
+    assert (a.lr_factor, a.lr_thresh, a.lr_patience, a.earlystop_min_delta, a.lowpass_ntaps) == (0.9, 1e-5, 100, 1.0, 7)
+    b = parse_arguments(["--imgdir", "d", "--datadim", "3d", "--upsample", "linear", "-e", "10", "--param_noise"])
+    assert b.upsample == "trilinear" and b.patch_shape == [-1, -1, -1] and b.epochs == 10 and b.param_noise is False
+    c = parse_arguments(["--imgdir", "d", "--datadim", "2.5d", "--upsample", "linear", "--iter", "7"])
+    assert c.upsample == "bilinear" and c.epochs == 7
+    assert parse_arguments(["--imgdir", "d", "--net", "skip"]).net == "skip"
+
+
+def test_parameter_matches_reference_args(golden):
+    """Every key the reference's Namespace has (recorded in the fixtures) exists here with the same value."""
+    g = golden("net_mulresunet3d_tiny_trilinear_mae")
+    ref = jstr(g["args"])
+    mine = vars(parse_arguments(jstr(g["argv"]) + ["--epochs", str(ref["epochs"])]))
+    for k, v in ref.items():
+        if k in ("param_noise",):       # the fixture run sets param_noise=False programmatically
+            continue
+        assert mine[k] == v, k
+    assert net_args_are_same(Namespace(**ref), Namespace(**mine))
+    other = dict(mine)
+    other["inputdepth"] = 3
+    assert not net_args_are_same(Namespace(**ref), Namespace(**other))
+
+
+# ---------------------------------------------------------------- data / patches ----------------------------------
+def test_patch_extractor_golden(golden):
+    for tag, c in golden("host")["pe"].items():
+        dim, stride = tuple(int(v) for v in c["dim"]), tuple(int(v) for v in c["stride"])
+        pe = u.PatchExtractor(dim=dim, stride=stride)
+        pa = pe.extract(c["vol"])
+        np.testing.assert_array_equal(pa, c["patches"])
+        assert pe.in_content_cropped_shape == tuple(c["cropped_shape"])
+        assert u.count_patches(c["vol"].shape, dim, stride) == int(c["count"])
+        assert u.patch_array_shape(c["vol"].shape, dim, stride) == tuple(c["array_shape"])
+        np.testing.assert_allclose(pe.reconstruct(c["patches2"]), c["recon2"], rtol=1e-14, atol=1e-14)
+        org = u.window_origins(c["vol"].shape, dim, stride)
+        flat = pa.reshape((-1,) + dim)
+        for p, o in zip(flat, org):        # plain definition: window w starts at w*stride, C order
+            np.testing.assert_array_equal(p, c["vol"][tuple(slice(a, a + d) for a, d in zip(o, dim))])
+
+
+def test_extract_and_reconstruct_patches_golden(golden, tmp_path):
+    g = golden("host")["data"]
+    np.save(tmp_path / "orig.npy", g["vol"])
+    np.save(tmp_path / "mask.npy", g["mask"])
+    nanvol = g["vol"].copy()
+    nanvol[g["mask"] == 0] = np.nan
+    np.save(tmp_path / "nan.npy", nanvol)
+    for tag in ("3d_bin", "3d_nan", "3d_full", "25d_xy", "25d_tx", "25d_ty"):
+        c = g[tag]
+        args = parse_arguments(["--imgdir", str(tmp_path), "--imgname", "orig.npy", "--outdir", "r_" + tag] + jstr(c["argv"]))
+        ps = D.extract_patches(args)
+        assert [p["name"] for p in ps] == jstr(c["names"])
+        np.testing.assert_array_equal(np.stack([p["image"] for p in ps]), c["images"])
+        np.testing.assert_array_equal(np.stack([p["mask"] for p in ps]), c["masks"])
+        if "recon" in c:
+            rdir = tmp_path / "results" / ("r_" + tag)
+            os.makedirs(rdir)
+            # The reference reads the result files in unsorted glob (= directory) order (data.py:99, SURVEY
+            # App. B.7); the fixture records that order.  We sort by name on purpose, so hand our reader the
+            # sequence the reference actually consumed: the k-th file of ITS order gets the k-th sorted name.
+            seq = [c["outputs"][int(n)] for n in jstr(c["glob_order"])]
+            for p, o in zip(ps, seq):
+                np.save(rdir / (p["name"] + "_run.npy"), {"output": o, "elapsed": "0h:0m:1s", "history": None, "device": "x"})
+            rec = D.reconstruct_patches(args, results_root=str(tmp_path / "results"))
+            np.testing.assert_allclose(rec, c["recon"], rtol=1e-13, atol=1e-13)
+
+
+def test_masks_metrics_generic_golden(golden):
+    g = golden("host")
+    np.testing.assert_array_equal(u.bool2bin(g["bool2bin"]["in"]), g["bool2bin"]["out"])
+    np.random.seed(0)
+    np.testing.assert_array_equal(u.build_mask(np.ones((6, 5, 4)), 0.5), g["build_mask"]["rand3d"])
+    np.random.seed(0)
+    np.testing.assert_array_equal(u.build_mask(np.ones((6, 10)), 0.3), g["build_mask"]["rand2d"])
+    np.testing.assert_array_equal(u.build_mask(np.ones((4, 12)), 0.66, regular=True), g["build_mask"]["reg_hi"])
+    np.testing.assert_array_equal(u.build_mask(np.ones((4, 12)), 0.25, regular=True), g["build_mask"]["reg_lo"])
+    np.random.seed(1)
+    np.testing.assert_array_equal(u.add_rand_mask(g["data"]["mask"], 0.3), g["add_rand_mask"]["out3d"])
+    m = g["metrics"]
+    a, b = torch.from_numpy(m["out"]), torch.from_numpy(m["tgt"])
+    assert abs(u.snr(a, b).item() - float(m["snr"])) < 1e-5 and abs(u.pcorr(a, b).item() - float(m["pcorr"])) < 1e-6
+    assert abs(u.snr(m["out"].astype(np.float64), m["tgt"].astype(np.float64)) - float(m["snr_np"])) < 1e-10
+    H = u.History(3000)
+    H.append((0.0123, 4.5, 0.87))
+    H.lr.append(1e-3)
+    assert H.log_message(0) == str(g["history"]["msg"]) and H.zfill == int(g["history"]["zfill"]) and len(H) == 1
+    gg = g["generic"]
+    assert [u.ten_digit(n) for n in (1, 9, 10, 343, 2001, 99999)] == list(gg["ten_digit"])
+    assert [u.sec2time(s) for s in (0, 59.9, 61, 3600, 6739.4)] == jstr(gg["sec2time"])
+    assert [u.time2sec(s) for s in ("0h:0m:59s", "1h:52m:19s")] == list(gg["time2sec"])
+    assert [u.nextpow2(n) for n in (1, 2, 3, 64, 65, 1000)] == list(gg["nextpow2"])
+    st = u.EarlyStopping(patience=40, min_delta=1.0, percentage=True)
+    got = [bool(st.step(l)) for l in g["earlystop"]["losses"]]
+    first = int(np.argmax(g["earlystop"]["stop"]))
+    assert got[:first + 1] == list(g["earlystop"]["stop"][:first + 1])
+    assert u.EarlyStopping(patience=3).step(float("nan")) is False      # first value only sets `best`
+    es = u.EarlyStopping(patience=3)
+    es.step(1.0)
+    assert es.step(float("nan")) is True                                  # NaN stops immediately (utils/torch.py:247)
+
+
+def test_args_json_roundtrip(tmp_path):
+    a = parse_arguments(["--imgdir", "d", "--datadim", "3d", "--patch_shape", "64", "64", "64"])
+    u.write_args(tmp_path / "args.txt", a)
+    assert vars(u.read_args(tmp_path / "args.txt")) == vars(a)
+    assert json.load(open(tmp_path / "args.txt"))["patch_shape"] == [64, 64, 64]
+
+
+def test_lines_known_answer(golden):
+    ln = golden("host")["lines"]
+    img = ln["original"].astype(np.float64)
+    std = torch.std(torch.from_numpy((img * ln["mask"]).astype(np.float32))).item()
+    assert "%.2e" % std == "3.62e-02"        # proof_of_concept_2D.ipynb:308
