@@ -52,24 +52,27 @@ __global__ __launch_bounds__(64) void loss_final_kernel(const double* __restrict
 
 // ---- Adam -----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(const dpi_adam_tensor* __restrict__ tensors, const int64_t* __restrict__ sizes,
-                                                   const float* __restrict__ step_lr, float beta1, float beta2, float eps,
+                                                   const float* __restrict__ step_lr, double beta1d, double beta2d, double epsd,
                                                    const int* __restrict__ active) {
   if (active && *active == 0) return;
   const dpi_adam_tensor t = tensors[blockIdx.y];
   const size_t n = (size_t)sizes[blockIdx.y];
   const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i0 >= n) return;
-  const float step = step_lr[0], lr = step_lr[1];
-  const float bc1 = 1.f - powf(beta1, step);
-  const float bc2s = sqrtf(1.f - powf(beta2, step));
-  const float step_size = lr / bc1;
+  // scalars exactly as torch.optim.Adam derives them: in double on the "host side", then rounded to fp32
+  const double step = (double)step_lr[0], lr = (double)step_lr[1];
+  const float beta2 = (float)beta2d, eps = (float)epsd;
+  const float omb1 = (float)(1.0 - beta1d), omb2 = (float)(1.0 - beta2d);
+  const float step_size = (float)(lr / (1.0 - pow(beta1d, step)));
+  const float bc2s = (float)sqrt(1.0 - pow(beta2d, step));
   for (size_t i = i0; i < n; i += (size_t)gridDim.x * 1024) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (i + k < n) {
         const float g = t.g[i + k];
-        const float m = beta1 * t.m[i + k] + (1.f - beta1) * g;
-        const float v = beta2 * t.v[i + k] + (1.f - beta2) * g * g;
+        const float m0 = t.m[i + k];
+        const float m = m0 + omb1 * (g - m0);                   // exp_avg.lerp_(grad, 1-beta1)
+        const float v = beta2 * t.v[i + k] + (omb2 * g) * g;    // mul_(beta2).addcmul_(g, g, value=1-beta2)
         t.m[i + k] = m;
         t.v[i + k] = v;
         const float denom = sqrtf(v) / bc2s + eps;
@@ -175,7 +178,7 @@ extern "C" int dpi_masked_loss(const float* out, const float* img, const float* 
 }
 
 extern "C" int dpi_adam_multi(const dpi_adam_tensor* tensors, const int64_t* sizes, int ntensors, const float* step_lr,
-                              float beta1, float beta2, float eps, const int* active, void* stream) {
+                              double beta1, double beta2, double eps, const int* active, void* stream) {
   DPI_REQUIRE(tensors && sizes && step_lr && ntensors > 0 && ntensors <= 65535, "adam_multi: bad argument");
   // grid.x is sized for the largest tensor by the caller-independent cap below; blocks past a tensor's end exit.
   adam_kernel<<<dim3(256, ntensors), 256, 0, (hipStream_t)stream>>>(tensors, sizes, step_lr, beta1, beta2, eps, active);

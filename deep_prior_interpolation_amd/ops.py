@@ -59,21 +59,55 @@ def desc_out_dims(d):
 # ------------------------------------------------------------------------------------------------
 # raw (non-autograd) launches, shared with the fused engine
 # ------------------------------------------------------------------------------------------------
+class KernelTimer:
+    """Brackets selected launches with HIP events on the stream they are launched on (torch's current stream),
+    for bench.py's roofline line.  `match(kind, desc)` selects launches; durations() gives milliseconds."""
+
+    def __init__(self, match):
+        self.match = match
+        self.events = []
+
+    def durations(self):
+        return [a.elapsed_time(b) for a, b in self.events]
+
+
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t
+
+
+def _timed(kind, d, launch):
+    if _timer is not None and _timer.match(kind, d):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        _timer.events.append((e0, e1))
+    else:
+        launch()
+
+
 def raw_conv_fwd(d, x, chain, w, bias, y, partials=None):
     L = _lib.load()
-    check(L.dpi_conv_fwd(C.byref(d), ptr(x), ptr(chain), ptr(w), ptr(bias), ptr(y), ptr(partials), stream()), "dpi_conv_fwd")
+    _timed("conv_fwd", d, lambda: check(L.dpi_conv_fwd(C.byref(d), ptr(x), ptr(chain), ptr(w), ptr(bias), ptr(y),
+                                                       ptr(partials), stream()), "dpi_conv_fwd"))
 
 
 def raw_conv_bwd_data(d, dy, w, dx, accumulate=False):
     L = _lib.load()
-    check(L.dpi_conv_bwd_data(C.byref(d), ptr(dy), ptr(w), ptr(dx), int(accumulate), stream()), "dpi_conv_bwd_data")
+    _timed("conv_bwd_data", d, lambda: check(L.dpi_conv_bwd_data(C.byref(d), ptr(dy), ptr(w), ptr(dx), int(accumulate),
+                                                                 stream()), "dpi_conv_bwd_data"))
 
 
 def raw_conv_bwd_weight(d, x, chain, dy, dw):
     L = _lib.load()
     n = L.dpi_conv_bwd_weight_ws_floats(C.byref(d))
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
-    check(L.dpi_conv_bwd_weight(C.byref(d), ptr(x), ptr(chain), ptr(dy), ptr(dw), ptr(ws), n, stream()), "dpi_conv_bwd_weight")
+    _timed("conv_bwd_weight", d, lambda: check(L.dpi_conv_bwd_weight(C.byref(d), ptr(x), ptr(chain), ptr(dy), ptr(dw),
+                                                                     ptr(ws), n, stream()), "dpi_conv_bwd_weight"))
 
 
 def raw_channel_sum(x, C_, V, out):

@@ -5,3 +5,4 @@ from .torch_utils import *      # noqa: F401,F403
 from .processing import *       # noqa: F401,F403
 from .patch_extractor import *  # noqa: F401,F403
 from .mask import *             # noqa: F401,F403
+from .synthetic import *        # noqa: F401,F403

@@ -135,11 +135,12 @@ int dpi_masked_loss(const float* out, const float* img, const float* mask, size_
  * Replaces torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8).step() (main.py:200,213) for a list of
  * tensors in ONE launch.  ptrs: device array of {p, g, m, v} pointers per tensor; sizes: element counts;
  * step_lr (device, float[2]): {step count as float (already incremented), lr}.  `active` (device int,
- * may be NULL): when *active == 0 the update is skipped (device-side early stop).
+ * may be NULL): when *active == 0 the update is skipped (device-side early stop).  Betas/eps are doubles so that
+ * 1-beta and the bias corrections are derived in double and then rounded, exactly as torch does on the host.
  */
 typedef struct { float* p; const float* g; float* m; float* v; } dpi_adam_tensor;
 int dpi_adam_multi(const dpi_adam_tensor* tensors, const int64_t* sizes, int ntensors,
-                   const float* step_lr, float beta1, float beta2, float eps, const int* active,
+                   const float* step_lr, double beta1, double beta2, double eps, const int* active,
                    void* stream);
 
 /* ---------------------------------------------------------------- input perturbation ------------

@@ -104,8 +104,9 @@ def test_net_trajectory(golden, name):
 
 
 def test_full_size_net_one_step_vs_oracle():
-    """Full default MulResUnet3D (5.9 M parameters) on a 32^3 patch: iteration-0 loss/metrics and all weight
-    gradients against the CPU oracle (same theta, same input)."""
+    """Full default MulResUnet3D (5.9 M parameters) on a 32^3 patch, same theta and input on both sides:
+    output, L1 loss and SNR against the CPU oracle; all conv-weight gradients (smooth MSE loss) against an fp64
+    run of the oracle, required to be in the same error class as the oracle's own fp32 run."""
     from deep_prior_interpolation_amd import ops, utils as u
     from deep_prior_interpolation_amd.architectures import get_net
     from deep_prior_interpolation_amd.parameter import parse_arguments
@@ -119,21 +120,32 @@ def test_full_size_net_one_step_vs_oracle():
     x = 0.1 * torch.randn((1, 64, 32, 32, 32), generator=gen)
     img = torch.randn((1, 1, 32, 32, 32), generator=gen)
     mask = (torch.rand((1, 1, 1, 32, 32), generator=gen) > 0.5).float().expand(1, 1, 32, 32, 32).contiguous()
-    S = O.NetState(init)
     cfg = {"ndim": 3, "filters": a.filters, "skip": a.skip, "upsample": "trilinear"}
-    out_r = O.net_forward(S, x, cfg)
-    loss_r = O.masked_loss(out_r, img, mask, "mae")
-    loss_r.backward()
+
+    def oracle(dtype):
+        S = O.NetState(init, dtype=dtype)
+        out = O.net_forward(S, x.to(dtype), cfg)
+        O.masked_loss(out, img.to(dtype), mask.to(dtype), "mse").backward()
+        return S, out.detach()
+
+    S32, o32 = oracle(torch.float32)
+    S64, o64 = oracle(torch.float64)
     net = net.to(DEV)
     out = net(x.to(DEV))
-    loss, met = ops.masked_loss(out, img.to(DEV), mask.to(DEV), "mae")
+    loss, met = ops.masked_loss(out, img.to(DEV), mask.to(DEV), "mse")
     loss.backward()
-    assert rel(out, out_r.detach().numpy()) < 1e-4
-    assert abs(loss.item() - loss_r.item()) < 1e-5 * abs(loss_r.item())
-    assert abs(met[1].item() - O.snr(out_r.detach(), img).item()) < 1e-3
-    worst = 0.0
+    assert rel(out, o64.numpy()) < 5e-5
+    l1, met1 = ops.masked_loss(out.detach(), img.to(DEV), mask.to(DEV), "mae")
+    assert abs(l1.item() - O.masked_loss(o64, img.double(), mask.double(), "mae").item()) < 1e-5 * abs(l1.item())
+    assert abs(met1[1].item() - O.snr(o64, img.double()).item()) < 1e-3
+    # The problem is ill-conditioned (BatchNorm over 2^3 voxels at the bottleneck): the oracle's own fp32 run sits
+    # 1e-4..6e-3 from its fp64 run.  Require the GPU to be in the same class: median error ratio < 2, worst tensor < 1e-2.
+    ratios, worst = [], 0.0
     for k, p in net.named_parameters():
-        gr = S.P[k].grad.numpy()
         if p.ndim > 1:                                   # conv weights carry the real gradient signal
-            worst = max(worst, rel(p.grad, gr))
-    assert worst < 2e-3, worst
+            g64 = S64.P[k].grad.numpy()
+            e_gpu, e_cpu = rel(p.grad, g64), rel(S32.P[k].grad, g64)
+            ratios.append(e_gpu / max(e_cpu, 1e-12))
+            worst = max(worst, e_gpu)
+    assert np.median(ratios) < 2.0, np.median(ratios)
+    assert worst < 1e-2, worst
