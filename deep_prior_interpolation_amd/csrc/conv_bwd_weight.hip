@@ -11,6 +11,12 @@
 #include "common.h"
 
 void dpi_conv_out_dims(const dpi_conv_desc* d, int* Do, int* Ho, int* Wo);
+size_t dpi_conv_bwd_weight_mfma_ws_floats(const dpi_conv_desc* d);
+int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws,
+                                 hipStream_t st);
+static int g_bw_mfma_min_cout = 8;
+extern "C" void dpi_set_bwd_weight_mfma_min_cout(int n) { g_bw_mfma_min_cout = n; }
+static bool bw_use_mfma(const dpi_conv_desc* d) { return d->k == 3 && d->stride == 1 && d->Cout >= g_bw_mfma_min_cout; }
 
 namespace {
 
@@ -258,6 +264,7 @@ BwPlan plan(const dpi_conv_desc* d) {
 
 extern "C" size_t dpi_conv_bwd_weight_ws_floats(const dpi_conv_desc* d) {
   if (!d || d->Cin <= 0 || d->Cout <= 0) return 0;
+  if (bw_use_mfma(d)) return dpi_conv_bwd_weight_mfma_ws_floats(d);
   const BwPlan p = plan(d);
   return (size_t)p.nchunks * d->Cout * d->Cin * d->kd * d->k * d->k;
 }
@@ -268,6 +275,13 @@ extern "C" int dpi_conv_bwd_weight(const dpi_conv_desc* d, const float* x, const
   DPI_REQUIRE((d->k == 1 || d->k == 3) && (d->kd == d->k || d->kd == 1) && (d->stride == 1 || d->stride == 2),
               "conv_bwd_weight: unsupported k=%d kd=%d stride=%d", d->k, d->kd, d->stride);
   hipStream_t st = (hipStream_t)stream;
+  if (bw_use_mfma(d)) {
+    if (ws_floats < dpi_conv_bwd_weight_mfma_ws_floats(d)) {
+      dpi_set_error("conv_bwd_weight: workspace %zu < %zu floats", ws_floats, dpi_conv_bwd_weight_mfma_ws_floats(d));
+      return DPI_E_WORKSPACE;
+    }
+    return dpi_conv_bwd_weight_mfma_run(d, x, x_chain, dy, dw, ws, st);
+  }
   const BwPlan p = plan(d);
   const size_t per = (size_t)d->Cout * d->Cin * d->kd * d->k * d->k;
   if (ws_floats < per * p.nchunks) {

@@ -433,6 +433,14 @@ int check_desc(const dpi_conv_desc* d) {
 
 }  // namespace
 
+// MFMA stencil path (conv_mfma.hip): k = 3, stride 1, enough output channels to fill a 16-row MFMA tile
+int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
+                      double* partials, bool flip, int accumulate, hipStream_t st);
+void dpi_mfma_variant(const dpi_conv_desc* d, int cout, int* nr, int* nh);
+int dpi_mfma_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth, int* ntw);
+static int g_mfma_min_cout = 8;
+extern "C" void dpi_set_mfma_min_cout(int n) { g_mfma_min_cout = n; }
+
 void dpi_conv_out_dims(const dpi_conv_desc* d, int* Do, int* Ho, int* Wo) {
   const int p = (d->k - 1) / 2, pd = (d->kd - 1) / 2, sd = d->kd > 1 ? d->stride : 1;
   *Do = (d->D + 2 * pd - d->kd) / sd + 1;
@@ -445,6 +453,11 @@ extern "C" int dpi_conv_fwd_stat_blocks(const dpi_conv_desc* d) {
   int Do, Ho, Wo;
   dpi_conv_out_dims(d, &Do, &Ho, &Wo);
   if (d->k == 1) return (int)cdivz((size_t)Do * Ho * Wo, 1024);
+  if (d->k == 3 && d->stride == 1 && d->Cout >= g_mfma_min_cout) {
+    int nr, nh, a, b, c;
+    dpi_mfma_variant(d, d->Cout, &nr, &nh);
+    return dpi_mfma_tiles(d, nr, nh, &a, &b, &c);
+  }
   const Geo g = conv_geo(d->kd, d->stride);
   return cdiv(Do, g.tz) * cdiv(Ho, g.ty) * cdiv(Wo, g.txow);
 }
@@ -458,6 +471,8 @@ static int conv_run(const dpi_conv_desc* d, const float* x, const float* chain, 
   const int taps = d->kd * d->k * d->k;
   const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
   const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
+  if (d->k == 3 && d->stride == 1 && cout >= g_mfma_min_cout)
+    return dpi_conv_mfma_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
   const int co_b = pick_co_b(cout);
   if (d->k == 1) {
     PwArgs a{x, chain, w, bias, y, partials, cin, cout, (size_t)Do * Ho * Wo, w_out, w_in, accumulate};

@@ -1,0 +1,409 @@
+// fp32-MFMA stencil convolution (k = 3, stride 1) for gfx950: forward, backward-data (FLIP) and backward-weight.
+//
+// The arithmetic engine is v_mfma_f32_16x16x4_f32 — f32 in / f32 accumulate, bit-for-bit a k-ordered fmaf chain, at
+// the fp32 vector rate — so numerics are those of a plain fp32 direct convolution; what MFMA buys is that one wave
+// per SIMD saturates the FMA pipe with ONE LDS read per 2048 FLOP and no scalar-load / SGPR-pair traffic (the limiter
+// of the VALU kernel in conv_direct.hip).  This is still a direct (stencil) convolution: the halo
+// tile of 4 input channels is staged in LDS exactly as in the VALU kernel (chain applied on load, zero padding
+// materialised) and each MFMA consumes one tap of 4 channels for 16 consecutive voxels x 16 output channels:
+//
+//     D[co 16][vox 16] += A[co 16][ci 4] * B[ci 4][vox 16]          (fixed tap)
+//        A = weights (registers, loaded once per 4-channel chunk), lane l: co = l&15, ci = l>>4
+//        B = halo tile (LDS), lane l: ci = l>>4, voxel = l&15 (+ tap offset) -> conflict-free ds_read_b32
+//          (channel stride = 16 mod 32 banks)
+//
+// Workgroup = 4 waves = output tile 4x8x32 (3-D; wave w owns depth slice w) or 1x32x32 (2-D; wave w owns 8 rows);
+// each wave keeps 16 voxel tiles x MT channel tiles of accumulators.  Every LDS value is read once per chunk and
+// feeds up to 3 (kh) x MT MFMAs.
+#include "common.h"
+
+void dpi_conv_out_dims(const dpi_conv_desc* d, int* Do, int* Ho, int* Wo);
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MArgs {
+  const float* __restrict__ x;
+  const float* __restrict__ chain;
+  const float* __restrict__ w;
+  const float* __restrict__ bias;
+  float* __restrict__ y;
+  double* __restrict__ partials;
+  int Cin, Cout;
+  int D, H, W;
+  int ntd, nth, ntw;
+  long w_out_stride, w_in_stride;
+  int accumulate;
+};
+
+// Tile geometry.  A wave owns NR output rows x NH 16-voxel column blocks; the 4 waves of a workgroup own
+//   3-D, NR = 8: 4 depth slices  (tile 4 x 8 x 16*NH)          3-D, NR = 2: 4 row pairs of ONE depth slice (tile 1 x 8 x 16*NH)
+//   2-D        : 4 bands of NR rows (tile 1 x 4*NR x 16*NH)
+// The small variants (NR = 2, NH = 1) exist so that the coarse levels of the U-Net (a few thousand voxels, hundreds of
+// channels) still produce >= 1000 waves.
+template <int KD, int NR, int NH>
+struct Geo {
+  static constexpr bool SLICES = (KD == 3 && NR == 8);          // waves split depth; otherwise they split rows
+  static constexpr int TZ = SLICES ? 4 : 1;
+  static constexpr int TY = SLICES ? NR : 4 * NR;
+  static constexpr int TW = 16 * NH;
+  static constexpr int ID = TZ + KD - 1;
+  static constexpr int IH = TY + 2;
+  static constexpr int IW = TW + 2;
+  static constexpr int RS = NH == 2 ? 36 : 20;                    // row stride (floats)
+  static constexpr int CS0 = ID * IH * RS;
+  static constexpr int CS = CS0 + ((16 - (CS0 % 32)) + 32) % 32;  // channel stride = 16 (mod 32 banks)
+  static constexpr int TILE = ID * IH * IW;
+  static constexpr int E = (TILE + 255) / 256;
+  static constexpr int NSTEP = KD * (NR + 2);                     // (kd, input row) pairs a wave walks per chunk
+  static constexpr int NB = 3 * NH;                               // LDS values per step
+};
+
+template <class G>
+__device__ __forceinline__ void tile_slots(int tid, int id0, int ih0, int iw0, int D, int H, int W, int (&goff)[G::E], int (&loff)[G::E]) {
+#pragma unroll
+  for (int e = 0; e < G::E; ++e) {
+    const int idx = tid + e * 256;
+    const int col = idx % G::IW, row = idx / G::IW;
+    const int hy = row % G::IH, dz = row / G::IH;
+    const int gd = id0 + dz, gh = ih0 + hy, gw = iw0 + col;
+    const bool ok = idx < G::TILE && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
+    goff[e] = ok ? (gd * H + gh) * W + gw : -1;
+    loff[e] = idx < G::TILE ? (dz * G::IH + hy) * G::RS + col : -1;
+  }
+}
+
+// issue the global loads of 4 channels [c0, c0+4) of the halo tile into registers (no wait here)
+template <class G>
+__device__ __forceinline__ void stage_load(float (&sr)[4][G::E], const float* __restrict__ x, int Cin, size_t V, int c0,
+                                           const int (&goff)[G::E]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int ci = c0 + c;
+    const bool cok = ci < Cin;
+    const float* __restrict__ xc = x + (size_t)(cok ? ci : 0) * V;
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) sr[c][e] = (cok && goff[e] >= 0) ? xc[goff[e]] : 0.f;
+  }
+}
+
+// registers -> LDS, applying the per-channel chain to in-volume samples (zero padding stays zero)
+template <class G>
+__device__ __forceinline__ void stage_store(float* lds, const float (&sr)[4][G::E], const float* __restrict__ chain, int Cin, int c0,
+                                            const int (&goff)[G::E], const int (&loff)[G::E]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int ci = c0 + c;
+    const Chain t = load_chain(chain, ci < Cin ? ci : 0);
+#pragma unroll
+    for (int e = 0; e < G::E; ++e)
+      if (loff[e] >= 0) lds[c * G::CS + loff[e]] = (chain && goff[e] >= 0 && ci < Cin) ? apply_chain(t, sr[c][e]) : sr[c][e];
+  }
+}
+
+// ---------------------------------------------------------------- forward / backward-data ---------------------------
+template <int KD, int NR, int NH, bool FLIP>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(MArgs a) {
+  using G = Geo<KD, NR, NH>;
+  constexpr int TAPS = KD * 9;
+  constexpr int PD = (KD - 1) / 2;
+  constexpr int NT = NR * NH;                       // voxel tiles per wave
+  __shared__ __attribute__((aligned(16))) float lds[4 * G::CS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  int bt = blockIdx.x;
+  const int tw_i = bt % a.ntw; bt /= a.ntw;
+  const int th_i = bt % a.nth; bt /= a.nth;
+  const int td_i = bt;
+  const int n0 = blockIdx.y * 16;
+  const int od0 = td_i * G::TZ, oh0 = th_i * G::TY, ow0 = tw_i * G::TW;
+  const size_t V = (size_t)a.D * a.H * a.W;
+
+  int goff[G::E], loff[G::E];
+  tile_slots<G>(tid, od0 - PD, oh0 - 1, ow0 - 1, a.D, a.H, a.W, goff, loff);
+
+  const int wz = G::SLICES ? wid : 0, wh = G::SLICES ? 0 : wid * NR;
+  const int lbase = lk * G::CS + (wz * G::IH + wh) * G::RS + lj;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // weights of a 4-channel chunk: lane (co = lj, ci = lk) keeps its TAPS filter taps
+  const int co_w = n0 + lj;
+  auto load_w = [&](float (&wr)[TAPS], int c0) {
+    const int ci = c0 + lk;
+    const bool ok = co_w < a.Cout && ci < a.Cin;
+    const float* __restrict__ wp = a.w + (ok ? co_w : 0) * a.w_out_stride + (ok ? ci : 0) * a.w_in_stride;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) wr[t] = ok ? wp[FLIP ? (TAPS - 1 - t) : t] : 0.f;
+  };
+
+  float wn[TAPS], sr[4][G::E];
+  load_w(wn, 0);
+  stage_load<G>(sr, a.x, a.Cin, V, 0, goff);
+
+  for (int c0 = 0; c0 < a.Cin; c0 += 4) {
+    float wr[TAPS];
+    __syncthreads();                                     // everyone is done reading the previous chunk
+    stage_store<G>(lds, sr, a.chain, a.Cin, c0, goff, loff);
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) wr[t] = wn[t];
+    __syncthreads();
+    if (c0 + 4 < a.Cin) {                                // prefetch the next chunk behind this chunk's MFMAs
+      load_w(wn, c0 + 4);
+      stage_load<G>(sr, a.x, a.Cin, V, c0 + 4, goff);
+    }
+    // software-pipelined walk over (kd, input row): LDS values of step s+1 are requested before the MFMAs of step s
+    float bc[G::NB], bn[G::NB];
+    auto load_b = [&](float (&b)[G::NB], int step) {
+      const int kd = step / (NR + 2), ir = step % (NR + 2);
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) b[h * 3 + kw] = lds[lbase + (kd * G::IH + ir) * G::RS + h * 16 + kw];
+    };
+    load_b(bc, 0);
+#pragma unroll
+    for (int step = 0; step < G::NSTEP; ++step) {
+      if (step + 1 < G::NSTEP) load_b(bn, step + 1);
+      const int kd = step / (NR + 2), ir = step % (NR + 2);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hr = ir - kh;                          // output row fed by this input row through tap kh
+        if (hr >= 0 && hr < NR) {
+#pragma unroll
+          for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+              acc[hr * NH + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(kd * 3 + kh) * 3 + kw], bc[h * 3 + kw], acc[hr * NH + h], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < G::NB; ++i) bc[i] = bn[i];
+    }
+  }
+
+  // ---- epilogue: D row = co (4*lk + r), D col = voxel lj -----------------------------------------------------------
+  const int Do = a.D, Ho = a.H, Wo = a.W;   // stride 1, 'same'
+  __shared__ double red[4][16][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = n0 + 4 * lk + r;
+    const bool cok = co < a.Cout;
+    const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
+      if (cok && od < Do && oh < Ho && ow < Wo) {
+        float* yp = a.y + (size_t)co * V + ((size_t)od * Ho + oh) * Wo + ow;
+        float v = acc[t][r] + bv;
+        if (a.accumulate) v += *yp;
+        *yp = v;
+        s += v;
+        q += (double)v * v;
+      }
+    }
+    if (a.partials) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+      if (lj == 0) { red[wid][4 * lk + r][0] = s; red[wid][4 * lk + r][1] = q; }
+    }
+  }
+  if (a.partials) {
+    __syncthreads();
+    if (tid < 32) {
+      const int c = tid >> 1, which = tid & 1;
+      const double rsum = red[0][c][which] + red[1][c][which] + red[2][c][which] + red[3][c][which];
+      if (n0 + c < a.Cout) a.partials[((size_t)blockIdx.x * a.Cout + n0 + c) * 2 + which] = rsum;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward-weight ----------------------------------
+//   dW[co][ci][tap] = sum_v dY[co][v] * X'[ci][v + tap]
+//   D[co 16][tap 16] += A[co 16][vox 4] * B[vox 4][tap 16]     per input channel, two tap tiles (27 of 32 columns used)
+//      A = dY straight from global memory (lane: co = l&15, voxel = 4s + (l>>4)); one load feeds 8 MFMAs
+//      B = X' halo tile in LDS, lane: voxel = 4s + (l>>4), tap = 16*tt + (l&15) -> per-lane tap offset
+struct BwMArgs {
+  const float* __restrict__ x;
+  const float* __restrict__ chain;
+  const float* __restrict__ dy;
+  float* __restrict__ ws;   // [nchunks][Cout][Cin][TAPS]
+  int Cin, Cout;
+  int D, H, W;
+  int ntd, nth, ntw, ntiles, tiles_per_chunk;
+};
+
+template <int KD>
+__global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
+  using G = Geo<KD, 8, 2>;
+  constexpr int TAPS = KD * 9;
+  constexpr int PD = (KD - 1) / 2;
+  constexpr int NTT = (TAPS + 15) / 16;       // tap tiles: 2 (3-D), 1 (2-D)
+  __shared__ __attribute__((aligned(16))) float lds[4 * G::CS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int c0 = blockIdx.y * 4, n0 = blockIdx.z * 16;
+  const size_t V = (size_t)a.D * a.H * a.W;
+  const int wz = KD == 3 ? wid : 0, wh = KD == 3 ? 0 : wid * 8;
+
+  // per-lane tap offsets inside the halo tile
+  int toff[NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) {
+    int tap = tt * 16 + lj;
+    if (tap >= TAPS) tap = TAPS - 1;           // unused columns: any valid address
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    toff[tt] = (kd * G::IH + kh) * G::RS + kw;
+  }
+  const int lbase = (wz * G::IH + wh) * G::RS + lk;
+  const int co_a = n0 + lj;
+  const bool co_ok = co_a < a.Cout;
+  const float* __restrict__ dyc = a.dy + (size_t)(co_ok ? co_a : 0) * V;
+
+  f32x4 acc[4][NTT];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) acc[c][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int t_begin = blockIdx.x * a.tiles_per_chunk;
+  const int t_end = min(t_begin + a.tiles_per_chunk, a.ntiles);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int bt = tile;
+    const int tw_i = bt % a.ntw; bt /= a.ntw;
+    const int th_i = bt % a.nth; bt /= a.nth;
+    const int td_i = bt;
+    const int od0 = td_i * G::TZ, oh0 = th_i * G::TY, ow0 = tw_i * G::TW;
+    int goff[G::E], loff[G::E];
+    float sr[4][G::E];
+    tile_slots<G>(tid, od0 - PD, oh0 - 1, ow0 - 1, a.D, a.H, a.W, goff, loff);
+    stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
+    __syncthreads();
+    stage_store<G>(lds, sr, a.chain, a.Cin, c0, goff, loff);
+    __syncthreads();
+    const int od = od0 + wz;
+#pragma unroll 2
+    for (int hr = 0; hr < 8; ++hr) {
+      const int oh = oh0 + wh + hr;
+      const bool row_ok = co_ok && od < a.D && oh < a.H;
+      const size_t rbase = ((size_t)od * a.H + oh) * a.W;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int ow = ow0 + 4 * s + lk;
+        const float g = (row_ok && ow < a.W) ? dyc[rbase + ow] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int tt = 0; tt < NTT; ++tt) {
+            const float b = lds[c * G::CS + lbase + hr * G::RS + 4 * s + toff[tt]];
+            acc[c][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(g, b, acc[c][tt], 0, 0, 0);
+          }
+      }
+    }
+  }
+  // ---- cross-wave reduction through LDS, then one partial per (chunk, co, ci, tap) ------------------------------------
+  __syncthreads();
+  float* red = lds;   // [4 waves][4 ci][NTT][4 r][64 lanes]
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(((wid * 4 + c) * NTT + tt) * 4 + r) * 64 + lane] = acc[c][tt][r];
+  __syncthreads();
+  for (int e = tid; e < 4 * NTT * 4 * 64; e += 256) {
+    const int l = e & 63, r = (e >> 6) & 3, tt = (e >> 8) % NTT, c = (e >> 8) / NTT;
+    const float sum = red[e] + red[e + 4 * NTT * 256] + red[e + 2 * 4 * NTT * 256] + red[e + 3 * 4 * NTT * 256];
+    const int co = n0 + 4 * (l >> 4) + r, tap = tt * 16 + (l & 15), ci = c0 + c;
+    if (co < a.Cout && ci < a.Cin && tap < TAPS)
+      a.ws[(((size_t)blockIdx.x * a.Cout + co) * a.Cin + ci) * TAPS + tap] = sum;
+  }
+}
+
+__global__ void reduce_chunks2_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n, int nchunks) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < nchunks; ++c) s += ws[(size_t)c * n + i];
+  out[i] = s;
+}
+
+}  // namespace
+
+// ---- host-side entry points used by the dispatchers in conv_direct.hip / conv_bwd_weight.hip ---------------------------
+// variant selection: big tiles while they still give >= 512 workgroups, else the small-tile kernels
+void dpi_mfma_variant(const dpi_conv_desc* d, int cout, int* nr, int* nh) {
+  const int tz = d->kd == 3 ? 4 : 1, ty = d->kd == 3 ? 8 : 32;
+  const long nb = (long)cdiv(d->D, tz) * cdiv(d->H, ty) * cdiv(d->W, 32) * cdiv(cout, 16);
+  if (nb >= 512) { *nr = 8; *nh = 2; }
+  else { *nr = 2; *nh = d->W > 16 ? 2 : 1; }
+}
+
+int dpi_mfma_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth, int* ntw) {
+  const bool slices = d->kd == 3 && nr == 8;
+  const int tz = slices ? 4 : 1, ty = slices ? nr : 4 * nr;
+  *ntd = cdiv(d->D, tz); *nth = cdiv(d->H, ty); *ntw = cdiv(d->W, 16 * nh);
+  return *ntd * *nth * *ntw;
+}
+
+template <int KD, bool FLIP>
+static void launch_variant(const MArgs& a, int nr, int nh, dim3 grid, hipStream_t st) {
+  if (nr == 8) conv_mfma_kernel<KD, 8, 2, FLIP><<<grid, 256, 0, st>>>(a);
+  else if (nh == 2) conv_mfma_kernel<KD, 2, 2, FLIP><<<grid, 256, 0, st>>>(a);
+  else conv_mfma_kernel<KD, 2, 1, FLIP><<<grid, 256, 0, st>>>(a);
+}
+
+int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
+                      double* partials, bool flip, int accumulate, hipStream_t st) {
+  const int taps = d->kd * 9;
+  const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
+  const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
+  MArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, accumulate};
+  int nr, nh;
+  dpi_mfma_variant(d, cout, &nr, &nh);
+  const int ntiles = dpi_mfma_tiles(d, nr, nh, &a.ntd, &a.nth, &a.ntw);
+  dim3 grid(ntiles, cdiv(cout, 16));
+  if (d->kd == 3) { if (flip) launch_variant<3, true>(a, nr, nh, grid, st); else launch_variant<3, false>(a, nr, nh, grid, st); }
+  else { if (flip) launch_variant<1, true>(a, nr, nh, grid, st); else launch_variant<1, false>(a, nr, nh, grid, st); }
+  return dpi_check_launch("conv_mfma");
+}
+
+struct MfmaBwPlan { int nchunks, tiles_per_chunk, ntiles, ntd, nth, ntw; };
+static MfmaBwPlan mfma_bw_plan(const dpi_conv_desc* d) {
+  MfmaBwPlan p{};
+  p.ntiles = dpi_mfma_tiles(d, 8, 2, &p.ntd, &p.nth, &p.ntw);
+  const size_t per = (size_t)d->Cout * d->Cin * d->kd * 9;
+  const size_t max_chunks_mem = per ? ((size_t)32 << 20) / per : 1;
+  const size_t blocks_other = (size_t)cdiv(d->Cin, 4) * cdiv(d->Cout, 16);
+  size_t want = cdivz(2048, blocks_other);
+  if (want > (size_t)p.ntiles) want = p.ntiles;
+  if (want > max_chunks_mem) want = max_chunks_mem;
+  if (want < 1) want = 1;
+  p.tiles_per_chunk = (int)cdivz(p.ntiles, want);
+  p.nchunks = cdiv(p.ntiles, p.tiles_per_chunk);
+  return p;
+}
+
+size_t dpi_conv_bwd_weight_mfma_ws_floats(const dpi_conv_desc* d) {
+  const MfmaBwPlan p = mfma_bw_plan(d);
+  return (size_t)p.nchunks * d->Cout * d->Cin * d->kd * 9;
+}
+
+int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws,
+                                 hipStream_t st) {
+  const MfmaBwPlan p = mfma_bw_plan(d);
+  BwMArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk};
+  dim3 grid(p.nchunks, cdiv(d->Cin, 4), cdiv(d->Cout, 16));
+  if (d->kd == 3) conv_bwd_weight_mfma_kernel<3><<<grid, 256, 0, st>>>(a);
+  else conv_bwd_weight_mfma_kernel<1><<<grid, 256, 0, st>>>(a);
+  if (int e = dpi_check_launch("conv_bwd_weight_mfma")) return e;
+  const size_t per = (size_t)d->Cout * d->Cin * d->kd * 9;
+  reduce_chunks2_kernel<<<(unsigned)cdivz(per, 256), 256, 0, st>>>(ws, dw, per, p.nchunks);
+  return dpi_check_launch("reduce_chunks");
+}

@@ -74,6 +74,11 @@ size_t dpi_conv_bwd_weight_ws_floats(const dpi_conv_desc* d);
 int dpi_conv_bwd_weight(const dpi_conv_desc* d, const float* x, const float* x_chain, const float* dy,
                         float* dw, float* ws, size_t ws_floats, void* stream);
 
+/* Dispatch thresholds (A/B testing): k=3 stride-1 convolutions with at least this many output channels run the
+ * fp32-MFMA stencil kernels (conv_mfma.hip), fewer use the VALU kernels.  Default 8. */
+void dpi_set_mfma_min_cout(int n);
+void dpi_set_bwd_weight_mfma_min_cout(int n);
+
 /* ---------------------------------------------------------------- BatchNorm / activations -------
  * Replaces nn.BatchNorm3d/2d in training mode (base.py:164,214; mulresunet.py:80-81,104,225) and
  * LeakyReLU(0.2) (base.py:102), plus their backward.

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of single convolution launches through the C ABI (HIP events on the launch stream).
+
+    python tools/bench_conv.py [--cases name ...] [--reps 10] [--mfma-min-cout 8] [--shape 256 128 128]
+"""
+import argparse
+import ctypes as C
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from deep_prior_interpolation_amd import _lib, ops  # noqa: E402
+
+CASES = {  # name: (Cin, Cout, k, stride, level)  level = spatial down-sampling exponent
+    "enc0_64_4": (64, 4, 3, 1, 0), "enc0_4_8": (4, 8, 3, 1, 0), "enc0_8_13": (8, 13, 3, 1, 0), "res0_25_16": (25, 16, 3, 1, 0),
+    "dec0_67_4": (67, 4, 3, 1, 0), "out_25_1": (25, 1, 3, 1, 0), "down0_25_25": (25, 25, 3, 2, 0),
+    "enc1_25_8": (25, 8, 3, 1, 1), "enc1_8_17": (8, 17, 3, 1, 1), "enc1_17_26": (17, 26, 3, 1, 1), "res1_51_32": (51, 32, 3, 1, 1),
+    "dec1_137_8": (137, 8, 3, 1, 1), "down1_51_51": (51, 51, 3, 2, 1),
+    "enc2_51_17": (51, 17, 3, 1, 2), "enc2_35_53": (35, 53, 3, 1, 2), "res2_105_64": (105, 64, 3, 1, 2), "dec2_276_17": (276, 17, 3, 1, 2),
+    "enc3_71_106": (71, 106, 3, 1, 3), "res3_212_128": (212, 128, 3, 1, 3), "enc4_142_213": (142, 213, 3, 1, 4),
+    "sc0_64_25": (64, 25, 1, 1, 0), "sc0_67_25": (67, 25, 1, 1, 0), "res0_25_16_k1": (25, 16, 1, 1, 0), "sc1_137_51": (137, 51, 1, 1, 1),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", nargs="*", default=["res0_25_16", "enc0_8_13", "enc0_64_4", "dec0_67_4", "res1_51_32", "down0_25_25", "sc0_64_25"])
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--shape", type=int, nargs=3, default=[256, 128, 128])
+    ap.add_argument("--mfma-min-cout", type=int, default=None)
+    ap.add_argument("--bw-mfma-min-cout", type=int, default=None)
+    ap.add_argument("--which", nargs="*", default=["fwd", "bwd_data", "bwd_weight"])
+    a = ap.parse_args()
+    L = _lib.load()
+    if a.mfma_min_cout is not None:
+        L.dpi_set_mfma_min_cout(a.mfma_min_cout)
+    if a.bw_mfma_min_cout is not None:
+        L.dpi_set_bwd_weight_mfma_min_cout(a.bw_mfma_min_cout)
+    dev = "cuda"
+    print("%-16s %-10s %10s %9s %8s" % ("case", "kernel", "ms", "TFLOP/s", "GB/s(alg)"))
+    for name in a.cases:
+        cin, cout, k, s, lvl = CASES[name]
+        shp = tuple(max(1, n >> lvl) for n in a.shape)
+        x = torch.randn((1, cin) + shp, device=dev)
+        w = torch.randn((cout, cin, k, k, k), device=dev) * 0.05
+        b = torch.randn(cout, device=dev)
+        d = ops.make_desc(x, w, s)
+        osh = ops.desc_out_dims(d)
+        y = torch.empty((1, cout) + osh, device=dev)
+        dy = torch.randn_like(y)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        vo = osh[0] * osh[1] * osh[2]
+        flop = 2.0 * cin * k ** 3 * cout * vo
+        byt = 4.0 * (x.numel() + y.numel())
+        fns = {"fwd": lambda: ops.raw_conv_fwd(d, x, None, w, b, y), "bwd_data": lambda: ops.raw_conv_bwd_data(d, dy, w, dx),
+               "bwd_weight": lambda: ops.raw_conv_bwd_weight(d, x, None, dy, dw)}
+        for which in a.which:
+            fn = fns[which]
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.reps
+            print("%-16s %-10s %10.4f %9.2f %8.0f" % (name, which, ms, flop / ms / 1e9, byt / ms / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    main()
