@@ -16,7 +16,7 @@ int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const f
                                  hipStream_t st);
 static int g_bw_mfma_min_cout = 8;
 extern "C" void dpi_set_bwd_weight_mfma_min_cout(int n) { g_bw_mfma_min_cout = n; }
-static bool bw_use_mfma(const dpi_conv_desc* d) { return d->k == 3 && d->stride == 1 && d->Cout >= g_bw_mfma_min_cout; }
+static bool bw_use_mfma(const dpi_conv_desc* d) { return d->k == 3 && d->Cout >= g_bw_mfma_min_cout; }
 
 namespace {
 

@@ -436,6 +436,7 @@ int check_desc(const dpi_conv_desc* d) {
 // MFMA stencil path (conv_mfma.hip): k = 3, stride 1, enough output channels to fill a 16-row MFMA tile
 int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
                       double* partials, bool flip, int accumulate, hipStream_t st);
+int dpi_conv_bwd_data_s2_mfma_run(const dpi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, hipStream_t st);
 void dpi_mfma_variant(const dpi_conv_desc* d, int cout, int* nr, int* nh);
 int dpi_mfma_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth, int* ntw);
 static int g_mfma_min_cout = 8;
@@ -453,7 +454,7 @@ extern "C" int dpi_conv_fwd_stat_blocks(const dpi_conv_desc* d) {
   int Do, Ho, Wo;
   dpi_conv_out_dims(d, &Do, &Ho, &Wo);
   if (d->k == 1) return (int)cdivz((size_t)Do * Ho * Wo, 1024);
-  if (d->k == 3 && d->stride == 1 && d->Cout >= g_mfma_min_cout) {
+  if (d->k == 3 && d->Cout >= g_mfma_min_cout) {
     int nr, nh, a, b, c;
     dpi_mfma_variant(d, d->Cout, &nr, &nh);
     return dpi_mfma_tiles(d, nr, nh, &a, &b, &c);
@@ -471,7 +472,7 @@ static int conv_run(const dpi_conv_desc* d, const float* x, const float* chain, 
   const int taps = d->kd * d->k * d->k;
   const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
   const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
-  if (d->k == 3 && d->stride == 1 && cout >= g_mfma_min_cout)
+  if (d->k == 3 && cout >= g_mfma_min_cout && (d->stride == 1 || !flip))
     return dpi_conv_mfma_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
   const int co_b = pick_co_b(cout);
   if (d->k == 1) {
@@ -507,6 +508,7 @@ extern "C" int dpi_conv_bwd_data(const dpi_conv_desc* d, const float* dy, const 
   DPI_REQUIRE(dy && w && dx, "conv_bwd_data: null tensor");
   hipStream_t st = (hipStream_t)stream;
   if (d->stride == 1) return conv_run(d, dy, nullptr, w, nullptr, dx, nullptr, true, accumulate, st);
+  if (d->Cin >= g_mfma_min_cout) return dpi_conv_bwd_data_s2_mfma_run(d, dy, w, dx, accumulate, st);
   int Do, Ho, Wo;
   dpi_conv_out_dims(d, &Do, &Ho, &Wo);
   BwdS2Args a{dy, w, dx, d->Cin, d->Cout, d->D, d->H, d->W, Do, Ho, Wo, d->kd, accumulate};

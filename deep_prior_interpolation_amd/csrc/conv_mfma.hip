@@ -42,21 +42,26 @@ struct MArgs {
 //   2-D        : 4 bands of NR rows (tile 1 x 4*NR x 16*NH)
 // The small variants (NR = 2, NH = 1) exist so that the coarse levels of the U-Net (a few thousand voxels, hundreds of
 // channels) still produce >= 1000 waves.
-template <int KD, int NR, int NH>
+template <int KD, int NR, int NH, int S = 1>
 struct Geo {
   static constexpr bool SLICES = (KD == 3 && NR == 8);          // waves split depth; otherwise they split rows
-  static constexpr int TZ = SLICES ? 4 : 1;
+  static constexpr int SD = KD == 3 ? S : 1;
+  static constexpr int TZ = SLICES ? 4 : 1;                      // output tile
   static constexpr int TY = SLICES ? NR : 4 * NR;
   static constexpr int TW = 16 * NH;
-  static constexpr int ID = TZ + KD - 1;
-  static constexpr int IH = TY + 2;
-  static constexpr int IW = TW + 2;
-  static constexpr int RS = NH == 2 ? 36 : 20;                    // row stride (floats)
+  static constexpr int ID = (TZ - 1) * SD + KD;                  // input (halo) tile
+  static constexpr int IH = (TY - 1) * S + 3;
+  static constexpr int IW = (TW - 1) * S + 3;
+  static constexpr int RS = (IW + 3) & ~3;                        // row stride (floats)
   static constexpr int CS0 = ID * IH * RS;
-  static constexpr int CS = CS0 + ((16 - (CS0 % 32)) + 32) % 32;  // channel stride = 16 (mod 32 banks)
+  // lanes of one ds_read_b32 group are 16 voxels (lane stride S) x 2 channels: channel stride = 16 (mod 32 banks) for
+  // unit stride, odd (= 1 mod 32) for stride 2 (even banks for one channel, odd banks for the other)
+  static constexpr int CSM = S == 1 ? 16 : 1;
+  static constexpr int CS = CS0 + ((CSM - (CS0 % 32)) + 32) % 32;
   static constexpr int TILE = ID * IH * IW;
   static constexpr int E = (TILE + 255) / 256;
-  static constexpr int NSTEP = KD * (NR + 2);                     // (kd, input row) pairs a wave walks per chunk
+  static constexpr int NROW = (NR - 1) * S + 3;                   // input rows a wave's band touches
+  static constexpr int NSTEP = KD * NROW;                         // (kd, input row) pairs a wave walks per chunk
   static constexpr int NB = 3 * NH;                               // LDS values per step
 };
 
@@ -103,9 +108,9 @@ __device__ __forceinline__ void stage_store(float* lds, const float (&sr)[4][G::
 }
 
 // ---------------------------------------------------------------- forward / backward-data ---------------------------
-template <int KD, int NR, int NH, bool FLIP>
+template <int KD, int NR, int NH, bool FLIP, int S = 1>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(MArgs a) {
-  using G = Geo<KD, NR, NH>;
+  using G = Geo<KD, NR, NH, S>;
   constexpr int TAPS = KD * 9;
   constexpr int PD = (KD - 1) / 2;
   constexpr int NT = NR * NH;                       // voxel tiles per wave
@@ -122,10 +127,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MArgs a) {
   const size_t V = (size_t)a.D * a.H * a.W;
 
   int goff[G::E], loff[G::E];
-  tile_slots<G>(tid, od0 - PD, oh0 - 1, ow0 - 1, a.D, a.H, a.W, goff, loff);
+  tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
 
   const int wz = G::SLICES ? wid : 0, wh = G::SLICES ? 0 : wid * NR;
-  const int lbase = lk * G::CS + (wz * G::IH + wh) * G::RS + lj;
+  const int lbase = lk * G::CS + (wz * G::SD * G::IH + wh * S) * G::RS + lj * S;
 
   f32x4 acc[NT];
 #pragma unroll
@@ -159,21 +164,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MArgs a) {
     // software-pipelined walk over (kd, input row): LDS values of step s+1 are requested before the MFMAs of step s
     float bc[G::NB], bn[G::NB];
     auto load_b = [&](float (&b)[G::NB], int step) {
-      const int kd = step / (NR + 2), ir = step % (NR + 2);
+      const int kd = step / G::NROW, ir = step % G::NROW;
 #pragma unroll
       for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) b[h * 3 + kw] = lds[lbase + (kd * G::IH + ir) * G::RS + h * 16 + kw];
+        for (int kw = 0; kw < 3; ++kw) b[h * 3 + kw] = lds[lbase + (kd * G::IH + ir) * G::RS + h * 16 * S + kw];
     };
     load_b(bc, 0);
 #pragma unroll
     for (int step = 0; step < G::NSTEP; ++step) {
       if (step + 1 < G::NSTEP) load_b(bn, step + 1);
-      const int kd = step / (NR + 2), ir = step % (NR + 2);
+      const int kd = step / G::NROW, ir = step % G::NROW;
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
-        const int hr = ir - kh;                          // output row fed by this input row through tap kh
-        if (hr >= 0 && hr < NR) {
+        const int hr = (ir - kh) / S;                    // output row fed by this input row through tap kh
+        if (ir - kh >= 0 && (ir - kh) % S == 0 && hr < NR) {
 #pragma unroll
           for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -187,7 +192,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MArgs a) {
   }
 
   // ---- epilogue: D row = co (4*lk + r), D col = voxel lj -----------------------------------------------------------
-  const int Do = a.D, Ho = a.H, Wo = a.W;   // stride 1, 'same'
+  const int Do = (a.D + 2 * PD - KD) / G::SD + 1, Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
+  const size_t Vo = (size_t)Do * Ho * Wo;
   __shared__ double red[4][16][2];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MArgs a) {
     for (int t = 0; t < NT; ++t) {
       const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
       if (cok && od < Do && oh < Ho && ow < Wo) {
-        float* yp = a.y + (size_t)co * V + ((size_t)od * Ho + oh) * Wo + ow;
+        float* yp = a.y + (size_t)co * Vo + ((size_t)od * Ho + oh) * Wo + ow;
         float v = acc[t][r] + bv;
         if (a.accumulate) v += *yp;
         *yp = v;
@@ -238,19 +244,23 @@ struct BwMArgs {
   int ntd, nth, ntw, ntiles, tiles_per_chunk;
 };
 
-template <int KD>
+template <int KD, int S, int NR, int NH>
 __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
-  using G = Geo<KD, 8, 2>;
+  using G = Geo<KD, NR, NH, S>;
   constexpr int TAPS = KD * 9;
   constexpr int PD = (KD - 1) / 2;
   constexpr int NTT = (TAPS + 15) / 16;       // tap tiles: 2 (3-D), 1 (2-D)
-  __shared__ __attribute__((aligned(16))) float lds[4 * G::CS];
+  constexpr int KS = 4 * NH;                  // k-steps (4 voxels each) per output row
+  constexpr int LDSF = 4 * G::CS > 4 * 4 * NTT * 256 ? 4 * G::CS : 4 * 4 * NTT * 256;
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lk = lane >> 4, lj = lane & 15;
   const int c0 = blockIdx.y * 4, n0 = blockIdx.z * 16;
   const size_t V = (size_t)a.D * a.H * a.W;
-  const int wz = KD == 3 ? wid : 0, wh = KD == 3 ? 0 : wid * 8;
+  const int Do = (a.D + 2 * PD - KD) / G::SD + 1, Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
+  const size_t Vo = (size_t)Do * Ho * Wo;
+  const int wz = G::SLICES ? wid : 0, wh = G::SLICES ? 0 : wid * NR;
 
   // per-lane tap offsets inside the halo tile
   int toff[NTT];
@@ -261,10 +271,10 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
     const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
     toff[tt] = (kd * G::IH + kh) * G::RS + kw;
   }
-  const int lbase = (wz * G::IH + wh) * G::RS + lk;
+  const int lbase = (wz * G::SD * G::IH + wh * S) * G::RS + lk * S;
   const int co_a = n0 + lj;
   const bool co_ok = co_a < a.Cout;
-  const float* __restrict__ dyc = a.dy + (size_t)(co_ok ? co_a : 0) * V;
+  const float* __restrict__ dyc = a.dy + (size_t)(co_ok ? co_a : 0) * Vo;
 
   f32x4 acc[4][NTT];
 #pragma unroll
@@ -274,35 +284,49 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
 
   const int t_begin = blockIdx.x * a.tiles_per_chunk;
   const int t_end = min(t_begin + a.tiles_per_chunk, a.ntiles);
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  int goff[G::E], loff[G::E];
+  float sr[4][G::E];
+  auto tile_origin = [&](int tile, int& od0, int& oh0, int& ow0) {
     int bt = tile;
     const int tw_i = bt % a.ntw; bt /= a.ntw;
     const int th_i = bt % a.nth; bt /= a.nth;
-    const int td_i = bt;
-    const int od0 = td_i * G::TZ, oh0 = th_i * G::TY, ow0 = tw_i * G::TW;
-    int goff[G::E], loff[G::E];
-    float sr[4][G::E];
-    tile_slots<G>(tid, od0 - PD, oh0 - 1, ow0 - 1, a.D, a.H, a.W, goff, loff);
+    od0 = bt * G::TZ; oh0 = th_i * G::TY; ow0 = tw_i * G::TW;
+  };
+  int od0, oh0, ow0;
+  if (t_begin < t_end) {
+    tile_origin(t_begin, od0, oh0, ow0);
+    tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
     stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
+  }
+  for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();
     stage_store<G>(lds, sr, a.chain, a.Cin, c0, goff, loff);
     __syncthreads();
-    const int od = od0 + wz;
+    const int cod = od0 + wz, coh0 = oh0 + wh, cow0 = ow0;
+    if (tile + 1 < t_end) {                                  // prefetch the next tile behind this tile's MFMAs
+      tile_origin(tile + 1, od0, oh0, ow0);
+      tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
+      stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
+    }
 #pragma unroll 2
-    for (int hr = 0; hr < 8; ++hr) {
-      const int oh = oh0 + wh + hr;
-      const bool row_ok = co_ok && od < a.D && oh < a.H;
-      const size_t rbase = ((size_t)od * a.H + oh) * a.W;
+    for (int hr = 0; hr < NR; ++hr) {
+      const int oh = coh0 + hr;
+      const bool row_ok = co_ok && cod < Do && oh < Ho;
+      const size_t rbase = ((size_t)cod * Ho + oh) * Wo;
+      float g[KS];
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const int ow = ow0 + 4 * s + lk;
-        const float g = (row_ok && ow < a.W) ? dyc[rbase + ow] : 0.f;
+      for (int s = 0; s < KS; ++s) {
+        const int ow = cow0 + 4 * s + lk;
+        g[s] = (row_ok && ow < Wo) ? dyc[rbase + ow] : 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
           for (int tt = 0; tt < NTT; ++tt) {
-            const float b = lds[c * G::CS + lbase + hr * G::RS + 4 * s + toff[tt]];
-            acc[c][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(g, b, acc[c][tt], 0, 0, 0);
+            const float b = lds[c * G::CS + lbase + hr * S * G::RS + 4 * s * S + toff[tt]];
+            acc[c][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[s], b, acc[c][tt], 0, 0, 0);
           }
       }
     }
@@ -326,6 +350,123 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- backward-data, stride 2 ---------------------------
+// dx[ci][i] = sum_co sum_k dy[co][(i + 1 - k) / 2] * w[co][ci][k]   (per axis; only integer quotients contribute).
+// Writing i = 2m + p: p = 0 uses tap k = 1 at o = m; p = 1 uses k = 2 at o = m and k = 0 at o = m + 1.  Each of the
+// 2^nd parity classes is therefore a small stride-1 convolution of dy over the m grid (1/2/4/8 taps, 27 in total):
+//     D[ci 16][m 16] += A[ci 16][co 4] * B[co 4][m 16 (+shift)]
+// A = weights in registers (lane: ci = l&15, co = l>>4), B = dy halo tile (one extra sample per axis) in LDS.
+// Workgroup = m tile 1 x 8 x 16 (3-D) / 1 x 8 x 16 (2-D), wave = 2 rows, all parity classes of those rows.
+struct BdS2Args {
+  const float* __restrict__ dy;
+  const float* __restrict__ w;     // [Cout][Cin][TAPS]
+  float* __restrict__ dx;
+  int Cin, Cout;
+  int D, H, W, Do, Ho, Wo;
+  int ntd, nth, ntw;
+  int accumulate;
+};
+
+template <int KD>
+__global__ __launch_bounds__(256) void conv_bwd_data_s2_mfma_kernel(BdS2Args a) {
+  constexpr int TAPS = KD * 9;
+  constexpr int NCLS = KD == 3 ? 8 : 4;
+  constexpr int ID = KD == 3 ? 2 : 1, IH = 9, IW = 17, RS = 20;
+  constexpr int CS0 = ID * IH * RS;
+  constexpr int CS = CS0 + ((16 - (CS0 % 32)) + 32) % 32;
+  constexpr int TILE = ID * IH * IW;
+  constexpr int E = (TILE + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float lds[4 * CS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  int bt = blockIdx.x;
+  const int tw_i = bt % a.ntw; bt /= a.ntw;
+  const int th_i = bt % a.nth; bt /= a.nth;
+  const int md0 = bt, mh0 = th_i * 8, mw0 = tw_i * 16;
+  const int n0 = blockIdx.y * 16;
+  const size_t Vo = (size_t)a.Do * a.Ho * a.Wo, V = (size_t)a.D * a.H * a.W;
+
+  int goff[E], loff[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int idx = tid + e * 256;
+    const int col = idx % IW, row = idx / IW;
+    const int hy = row % IH, dz = row / IH;
+    const int gd = md0 + dz, gh = mh0 + hy, gw = mw0 + col;
+    const bool ok = idx < TILE && gd < a.Do && gh < a.Ho && gw < a.Wo;
+    goff[e] = ok ? (gd * a.Ho + gh) * a.Wo + gw : -1;
+    loff[e] = idx < TILE ? (dz * IH + hy) * RS + col : -1;
+  }
+  const int lbase = lk * CS + (wid * 2) * RS + lj;
+
+  f32x4 acc[NCLS][2];
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c) { acc[c][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[c][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  const int ci_w = n0 + lj;
+  for (int c0 = 0; c0 < a.Cout; c0 += 4) {
+    float wr[TAPS];
+    {
+      const int co = c0 + lk;
+      const bool ok = ci_w < a.Cin && co < a.Cout;
+      const float* __restrict__ wp = a.w + ((size_t)(ok ? co : 0) * a.Cin + (ok ? ci_w : 0)) * TAPS;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) wr[t] = ok ? wp[t] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int co = c0 + c;
+      const float* __restrict__ gc = a.dy + (size_t)(co < a.Cout ? co : 0) * Vo;
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (loff[e] >= 0) lds[c * CS + loff[e]] = (co < a.Cout && goff[e] >= 0) ? gc[goff[e]] : 0.f;
+    }
+    __syncthreads();
+    // every (shift_d, shift_h, shift_w, row) sample of the tile feeds the classes whose parity allows that shift
+#pragma unroll
+    for (int sd = 0; sd < ID; ++sd)
+#pragma unroll
+      for (int ir = 0; ir < 3; ++ir)                       // dy row offset inside this wave's 2-row band (+1 halo)
+#pragma unroll
+        for (int sw = 0; sw < 2; ++sw) {
+          const float b = lds[lbase + (sd * IH + ir) * RS + sw];
+#pragma unroll
+          for (int sh = 0; sh < 2; ++sh) {
+            const int row = ir - sh;                         // m-row (0/1) that reads dy row `ir` with shift sh
+            if (row < 0 || row > 1) continue;
+#pragma unroll
+            for (int cls = 0; cls < NCLS; ++cls) {
+              const int pw = cls & 1, ph = (cls >> 1) & 1, pd = KD == 3 ? (cls >> 2) & 1 : 0;
+              if ((sw && !pw) || (sh && !ph) || (sd && !pd)) continue;   // even parity has no shifted tap
+              const int kw = pw ? (sw ? 0 : 2) : 1, kh = ph ? (sh ? 0 : 2) : 1, kd = KD == 3 ? (pd ? (sd ? 0 : 2) : 1) : 0;
+              acc[cls][row] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(kd * 3 + kh) * 3 + kw], b, acc[cls][row], 0, 0, 0);
+            }
+          }
+        }
+  }
+  // ---- store: D row = ci (4*lk + r), D col = m column lj ---------------------------------------------------------------
+#pragma unroll
+  for (int cls = 0; cls < NCLS; ++cls) {
+    const int pw = cls & 1, ph = (cls >> 1) & 1, pd = KD == 3 ? (cls >> 2) & 1 : 0;
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+      const int id = KD == 3 ? 2 * md0 + pd : md0, ih = 2 * (mh0 + wid * 2 + row) + ph, iw = 2 * (mw0 + lj) + pw;
+      if (id < a.D && ih < a.H && iw < a.W) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ci = n0 + 4 * lk + r;
+          if (ci < a.Cin) {
+            float* p = a.dx + (size_t)ci * V + ((size_t)id * a.H + ih) * a.W + iw;
+            *p = a.accumulate ? *p + acc[cls][row][r] : acc[cls][row][r];
+          }
+        }
+      }
+    }
+  }
+}
+
 __global__ void reduce_chunks2_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n, int nchunks) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -337,23 +478,35 @@ __global__ void reduce_chunks2_kernel(const float* __restrict__ ws, float* __res
 }  // namespace
 
 // ---- host-side entry points used by the dispatchers in conv_direct.hip / conv_bwd_weight.hip ---------------------------
-// variant selection: big tiles while they still give >= 512 workgroups, else the small-tile kernels
+// variant selection: big tiles while they still give >= 512 workgroups, else the small-tile kernels; stride 2 always
+// uses the small tiles (its halo tile is 4x larger)
 void dpi_mfma_variant(const dpi_conv_desc* d, int cout, int* nr, int* nh) {
+  int Do, Ho, Wo;
+  dpi_conv_out_dims(d, &Do, &Ho, &Wo);
   const int tz = d->kd == 3 ? 4 : 1, ty = d->kd == 3 ? 8 : 32;
-  const long nb = (long)cdiv(d->D, tz) * cdiv(d->H, ty) * cdiv(d->W, 32) * cdiv(cout, 16);
-  if (nb >= 512) { *nr = 8; *nh = 2; }
-  else { *nr = 2; *nh = d->W > 16 ? 2 : 1; }
+  const long nb = (long)cdiv(Do, tz) * cdiv(Ho, ty) * cdiv(Wo, 32) * cdiv(cout, 16);
+  if (nb >= 512 && d->stride == 1) { *nr = 8; *nh = 2; }
+  else { *nr = 2; *nh = Wo > 16 ? 2 : 1; }
 }
 
 int dpi_mfma_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth, int* ntw) {
+  int Do, Ho, Wo;
+  dpi_conv_out_dims(d, &Do, &Ho, &Wo);
   const bool slices = d->kd == 3 && nr == 8;
   const int tz = slices ? 4 : 1, ty = slices ? nr : 4 * nr;
-  *ntd = cdiv(d->D, tz); *nth = cdiv(d->H, ty); *ntw = cdiv(d->W, 16 * nh);
+  *ntd = cdiv(Do, tz); *nth = cdiv(Ho, ty); *ntw = cdiv(Wo, 16 * nh);
   return *ntd * *nth * *ntw;
 }
 
 template <int KD, bool FLIP>
-static void launch_variant(const MArgs& a, int nr, int nh, dim3 grid, hipStream_t st) {
+static void launch_variant(const MArgs& a, int nr, int nh, int stride, dim3 grid, hipStream_t st) {
+  if (stride == 2) {
+    if constexpr (!FLIP) {
+      if (nh == 2) conv_mfma_kernel<KD, 2, 2, false, 2><<<grid, 256, 0, st>>>(a);
+      else conv_mfma_kernel<KD, 2, 1, false, 2><<<grid, 256, 0, st>>>(a);
+    }
+    return;
+  }
   if (nr == 8) conv_mfma_kernel<KD, 8, 2, FLIP><<<grid, 256, 0, st>>>(a);
   else if (nh == 2) conv_mfma_kernel<KD, 2, 2, FLIP><<<grid, 256, 0, st>>>(a);
   else conv_mfma_kernel<KD, 2, 1, FLIP><<<grid, 256, 0, st>>>(a);
@@ -369,15 +522,17 @@ int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain
   dpi_mfma_variant(d, cout, &nr, &nh);
   const int ntiles = dpi_mfma_tiles(d, nr, nh, &a.ntd, &a.nth, &a.ntw);
   dim3 grid(ntiles, cdiv(cout, 16));
-  if (d->kd == 3) { if (flip) launch_variant<3, true>(a, nr, nh, grid, st); else launch_variant<3, false>(a, nr, nh, grid, st); }
-  else { if (flip) launch_variant<1, true>(a, nr, nh, grid, st); else launch_variant<1, false>(a, nr, nh, grid, st); }
+  if (d->kd == 3) { if (flip) launch_variant<3, true>(a, nr, nh, d->stride, grid, st); else launch_variant<3, false>(a, nr, nh, d->stride, grid, st); }
+  else { if (flip) launch_variant<1, true>(a, nr, nh, d->stride, grid, st); else launch_variant<1, false>(a, nr, nh, d->stride, grid, st); }
   return dpi_check_launch("conv_mfma");
 }
 
-struct MfmaBwPlan { int nchunks, tiles_per_chunk, ntiles, ntd, nth, ntw; };
+struct MfmaBwPlan { int nchunks, tiles_per_chunk, ntiles, ntd, nth, ntw, nr, nh; };
 static MfmaBwPlan mfma_bw_plan(const dpi_conv_desc* d) {
   MfmaBwPlan p{};
-  p.ntiles = dpi_mfma_tiles(d, 8, 2, &p.ntd, &p.nth, &p.ntw);
+  if (d->stride == 1) { p.nr = 8; p.nh = 2; }
+  else { int Do, Ho, Wo; dpi_conv_out_dims(d, &Do, &Ho, &Wo); p.nr = 2; p.nh = Wo > 16 ? 2 : 1; }
+  p.ntiles = dpi_mfma_tiles(d, p.nr, p.nh, &p.ntd, &p.nth, &p.ntw);
   const size_t per = (size_t)d->Cout * d->Cin * d->kd * 9;
   const size_t max_chunks_mem = per ? ((size_t)32 << 20) / per : 1;
   const size_t blocks_other = (size_t)cdiv(d->Cin, 4) * cdiv(d->Cout, 16);
@@ -400,10 +555,30 @@ int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const f
   const MfmaBwPlan p = mfma_bw_plan(d);
   BwMArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk};
   dim3 grid(p.nchunks, cdiv(d->Cin, 4), cdiv(d->Cout, 16));
-  if (d->kd == 3) conv_bwd_weight_mfma_kernel<3><<<grid, 256, 0, st>>>(a);
-  else conv_bwd_weight_mfma_kernel<1><<<grid, 256, 0, st>>>(a);
+  if (d->stride == 1) {
+    if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<grid, 256, 0, st>>>(a);
+    else conv_bwd_weight_mfma_kernel<1, 1, 8, 2><<<grid, 256, 0, st>>>(a);
+  } else if (p.nh == 2) {
+    if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 2, 2, 2><<<grid, 256, 0, st>>>(a);
+    else conv_bwd_weight_mfma_kernel<1, 2, 2, 2><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 2, 2, 1><<<grid, 256, 0, st>>>(a);
+    else conv_bwd_weight_mfma_kernel<1, 2, 2, 1><<<grid, 256, 0, st>>>(a);
+  }
   if (int e = dpi_check_launch("conv_bwd_weight_mfma")) return e;
   const size_t per = (size_t)d->Cout * d->Cin * d->kd * 9;
   reduce_chunks2_kernel<<<(unsigned)cdivz(per, 256), 256, 0, st>>>(ws, dw, per, p.nchunks);
   return dpi_check_launch("reduce_chunks");
+}
+
+int dpi_conv_bwd_data_s2_mfma_run(const dpi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, hipStream_t st) {
+  int Do, Ho, Wo;
+  dpi_conv_out_dims(d, &Do, &Ho, &Wo);
+  BdS2Args a{dy, w, dx, d->Cin, d->Cout, d->D, d->H, d->W, Do, Ho, Wo, 0, 0, 0, accumulate};
+  const int md = d->kd == 3 ? cdiv(d->D, 2) : d->D, mh = cdiv(d->H, 2), mw = cdiv(d->W, 2);
+  a.ntd = md; a.nth = cdiv(mh, 8); a.ntw = cdiv(mw, 16);
+  dim3 grid(a.ntd * a.nth * a.ntw, cdiv(d->Cin, 16));
+  if (d->kd == 3) conv_bwd_data_s2_mfma_kernel<3><<<grid, 256, 0, st>>>(a);
+  else conv_bwd_data_s2_mfma_kernel<1><<<grid, 256, 0, st>>>(a);
+  return dpi_check_launch("conv_bwd_data_s2_mfma");
 }

@@ -61,6 +61,9 @@ CONV_RANDOM = [
     (67, 4, (6, 10, 34), 3, 1), (25, 1, (8, 16, 32), 3, 1), (35, 71, (8, 8, 8), 3, 1), (71, 142, (4, 4, 4), 3, 1),
     (25, 25, (16, 16, 32), 3, 2), (51, 51, (9, 11, 13), 3, 2), (3, 5, (2, 2, 2), 3, 2), (5, 3, (1, 1, 1), 3, 1),
     (64, 25, (8, 16, 32), 1, 1), (137, 51, (5, 7, 9), 1, 1), (554, 35, (4, 4, 4), 1, 1), (25, 16, (8, 8, 33), 1, 1),
+    # MFMA paths: small-tile variants (few voxels), stride 2 with >= 8 channels, odd sizes, channel tails
+    (12, 9, (7, 9, 11), 3, 2), (9, 20, (8, 8, 40), 3, 2), (105, 64, (4, 8, 16), 3, 1), (17, 26, (6, 6, 6), 3, 1),
+    (16, 16, (3, 5, 17), 3, 1), (9, 33, (12, 16, 64), 3, 1), (212, 212, (2, 2, 2), 3, 2),
 ]
 
 
@@ -83,7 +86,9 @@ def test_conv_vs_oracle(ops, cin, cout, shape, k, stride):
     assert rel(bg.grad, br.grad) < 5e-6
 
 
-@pytest.mark.parametrize("cin,cout,shape,k,stride", [(5, 7, (1, 37, 41), 3, 1), (6, 6, (1, 33, 30), 3, 2), (9, 4, (1, 20, 24), 1, 1)])
+@pytest.mark.parametrize("cin,cout,shape,k,stride", [(5, 7, (1, 37, 41), 3, 1), (6, 6, (1, 33, 30), 3, 2), (9, 4, (1, 20, 24), 1, 1),
+                                                     (9, 12, (1, 33, 30), 3, 2), (13, 17, (1, 70, 45), 3, 1), (16, 8, (1, 9, 12), 3, 1),
+                                                     (10, 10, (1, 64, 64), 3, 2)])
 def test_conv2d_vs_oracle(ops, cin, cout, shape, k, stride):
     gen = torch.Generator().manual_seed(7)
     x = torch.randn((1, cin) + shape[1:], generator=gen)
