@@ -72,12 +72,11 @@ class _ConvBnActMixin:
 
     def forward(self, x):
         conv_m, bn, act = self._parts()
-        y = conv_m(x)
         if isinstance(act, hnn.LeakyReLU):
             from .. import ops
-            return ops.batch_norm(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                  act.negative_slope)
-        return act(bn(y))
+            return ops.conv_bn_act(x, conv_m.weight, conv_m.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                   bn.num_batches_tracked, conv_m._s, act.negative_slope)
+        return act(bn(conv_m(x)))
 
 
 class ConvBnAct3d(_ConvBnActMixin, Seq):

@@ -53,9 +53,15 @@ class MultiResBlock(nn.Module):
             out = self.dr(self.bn1(out))
         else:
             out = self.dr(out)
-        out = self.act(ops.add(self.shortcut(x), out))
-        if self.nd == 3:
-            out = self.bn2(out)
+        out = ops.add(self.shortcut(x), out)
+        if self.nd == 3 and isinstance(self.act, hnn.LeakyReLU):
+            b = self.bn2                                    # act -> bn2 as one chained pass
+            out = ops.batch_norm(out, b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked, 1.0,
+                                 self.act.negative_slope)
+        else:
+            out = self.act(out)
+            if self.nd == 3:
+                out = self.bn2(out)
         return self.dr(out)
 
 
@@ -83,8 +89,30 @@ class ResPath(nn.Module):
 
     def forward(self, x):
         if self.nd == 3:
-            return self.dr(self.bn(self.act(ops.add(self.conv1x1(x), self.conv3x3(x)))))
-        return self.net[2](self.dr(self.act(ops.add(self.net[0](x), self.net[1](x)))))
+            t, b = ops.add(self.conv1x1(x), self.conv3x3(x)), self.bn
+        else:
+            t, b = ops.add(self.net[0](x), self.net[1](x)), self.net[2]
+        if isinstance(self.act, hnn.LeakyReLU):                 # act -> bn as one chained pass
+            return self.dr(ops.batch_norm(t, b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked, 1.0,
+                                          self.act.negative_slope))
+        return self.dr(b(self.dr(self.act(t))))
+
+
+class DownPath(Seq):
+    """The `deeper` branch: stride-2 conv [-> BN] -> act -> dropout -> block -> [inner] -> upsample.  Same children and
+    names as a plain Seq; only the conv -> BN -> LeakyReLU head (3-D) is executed as one fused op."""
+
+    def forward(self, x):
+        mods = list(self._modules.values())
+        if (len(mods) >= 3 and isinstance(mods[1], (hnn.BatchNorm3d, hnn.BatchNorm2d)) and isinstance(mods[2], hnn.LeakyReLU)
+                and isinstance(mods[0], nn.Sequential)):
+            conv_m, bn, act = mods[0][0], mods[1], mods[2]
+            x = ops.conv_bn_act(x, conv_m.weight, conv_m.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                bn.num_batches_tracked, conv_m._s, act.negative_slope)
+            mods = mods[3:]
+        for m in mods:
+            x = m(x)
+        return x
 
 
 def _mulresunet(nd, num_input_channels, num_output_channels, num_channels_down, num_channels_up, num_channels_skip,
@@ -100,7 +128,7 @@ def _mulresunet(nd, num_input_channels, num_output_channels, num_channels_down, 
     cur.add(block)
     depth = block.out_dim
     for i in range(1, n_scales):
-        deeper, skip = Seq(), Seq()
+        deeper, skip = DownPath(), Seq()
         # the encoder block is constructed before the stride-2 conv (mulresunet.py:221-224): RNG order
         block = MultiResBlock(nd, num_channels_down[i], depth, alpha, act_fun, need_bias, dropout)
         deeper.add(conv_nd(nd, depth, depth, 3, stride=2, bias=need_bias))

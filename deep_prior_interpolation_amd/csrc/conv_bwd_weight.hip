@@ -218,12 +218,16 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_pw_kernel(BwPwArgs a) {
   }
 }
 
+// 8 lanes per output element: lane p sums chunks p, p+8, ... in order, then a fixed xor tree (deterministic)
 __global__ void reduce_chunks_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n, int nchunks) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = gid >> 3;
+  const int part = gid & 7;
   float s = 0.f;
-  for (int c = 0; c < nchunks; ++c) s += ws[(size_t)c * n + i];
-  out[i] = s;
+  if (i < n)
+    for (int c = part; c < nchunks; c += 8) s += ws[(size_t)c * n + i];
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  if (i < n && part == 0) out[i] = s;
 }
 
 struct BwPlan { int nchunks, tiles_per_chunk, ntiles, ntd, nth, ntw; size_t vox_per_chunk; };
@@ -238,7 +242,7 @@ BwPlan plan(const dpi_conv_desc* d) {
     const size_t V = (size_t)Do * Ho * Wo;
     const size_t units = cdivz(V, 1024);
     const size_t blocks_other = (size_t)cdiv(d->Cin, 4) * cdiv(d->Cout, 8);
-    size_t want = cdivz(2048, blocks_other);
+    size_t want = cdivz(1024, blocks_other);
     if (want > units) want = units;
     if (want > max_chunks_mem) want = max_chunks_mem;
     if (want < 1) want = 1;
@@ -251,7 +255,7 @@ BwPlan plan(const dpi_conv_desc* d) {
   p.ntd = cdiv(Do, tz); p.nth = cdiv(Ho, ty); p.ntw = cdiv(Wo, tw);
   p.ntiles = p.ntd * p.nth * p.ntw;
   const size_t blocks_other = (size_t)cdiv(d->Cin, 4) * cdiv(d->Cout, 4);
-  size_t want = cdivz(2048, blocks_other);
+  size_t want = cdivz(1024, blocks_other);
   if (want > (size_t)p.ntiles) want = p.ntiles;
   if (want > max_chunks_mem) want = max_chunks_mem;
   if (want < 1) want = 1;
@@ -307,6 +311,6 @@ extern "C" int dpi_conv_bwd_weight(const dpi_conv_desc* d, const float* x, const
     }
   }
   if (int e = dpi_check_launch("conv_bwd_weight")) return e;
-  reduce_chunks_kernel<<<(unsigned)cdivz(per, 256), 256, 0, st>>>(ws, dw, per, p.nchunks);
+  reduce_chunks_kernel<<<(unsigned)cdivz(per * 8, 256), 256, 0, st>>>(ws, dw, per, p.nchunks);
   return dpi_check_launch("reduce_chunks");
 }

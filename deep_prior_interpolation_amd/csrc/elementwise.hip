@@ -56,9 +56,9 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
 // ---- finalize: one wave per channel, fixed-order reduction of the block partials ----------------------------
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restrict__ partials, int nblk, int C, double count,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float eps, float momentum, float slope, float* running_mean,
-                                                         float* running_var, int64_t* nbt, float* __restrict__ mean_invstd,
-                                                         float* __restrict__ chain_out) {
+                                                         float eps, float momentum, float slope, int act_first,
+                                                         float* running_mean, float* running_var, int64_t* nbt,
+                                                         float* __restrict__ mean_invstd, float* __restrict__ chain_out) {
   const int c = blockIdx.x, lane = threadIdx.x;
   double s = 0.0, q = 0.0;
   for (int b = lane; b < nblk; b += 64) {
@@ -84,7 +84,8 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restric
       const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
       const float a = g * invstd;
       float* o = chain_out + (size_t)c * DPI_CHAIN_STRIDE;
-      o[0] = a; o[1] = bt - meanf * a; o[2] = slope; o[3] = 1.f; o[4] = 0.f;
+      if (act_first) { o[0] = 1.f; o[1] = 0.f; o[2] = slope; o[3] = a; o[4] = bt - meanf * a; }   // BN(act(x))
+      else { o[0] = a; o[1] = bt - meanf * a; o[2] = slope; o[3] = 1.f; o[4] = 0.f; }           // act(BN(x))
     }
   }
 }
@@ -108,13 +109,38 @@ __global__ __launch_bounds__(256) void chain_apply_kernel(const float* __restric
 }
 
 // ---- BatchNorm backward ------------------------------------------------------------------------------------
+// Generalised to the two fused forms the networks use (slopes of 1 disable them):
+//   pre_slope  (act -> BN):  u = act_pre(x) is what was normalised;  dx = du * act_pre'(x)
+//   post_slope (BN -> act):  the incoming gradient is w.r.t. act_post(BN(x));  g = dy * act_post'(gamma*xhat + beta)
+// so neither the activation output nor an intermediate gradient tensor is ever materialised.
+struct BnBwd {
+  float mean, invstd, a, pb, pre, post;
+};
+__device__ __forceinline__ BnBwd bn_bwd_consts(const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, float pre, float post, int C, int c) {
+  BnBwd k;
+  k.mean = mean_invstd[c]; k.invstd = mean_invstd[C + c];
+  k.a = (gamma ? gamma[c] : 1.f) * k.invstd;
+  k.pb = (beta ? beta[c] : 0.f) - k.mean * k.a;   // same expression as bn_finalize's chain shift: identical activation mask
+  k.pre = pre; k.post = post;
+  return k;
+}
+// returns xhat and the gradient w.r.t. the BN output proper
+__device__ __forceinline__ void bn_bwd_elem(const BnBwd& k, float x, float dy, float& xhat, float& g) {
+  const float u = x > 0.f ? x : x * k.pre;
+  xhat = (u - k.mean) * k.invstd;
+  const float yv = fmaf(k.a, u, k.pb);
+  g = (k.post == 1.f || yv > 0.f) ? dy : dy * k.post;
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                            const float* __restrict__ mean_invstd, int C, size_t V, int nblk,
-                                                            double* __restrict__ partials) {
+                                                            const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float pre, float post, int C, size_t V,
+                                                            int nblk, double* __restrict__ partials) {
   const int c = blockIdx.y, b = blockIdx.x;
   const size_t span = stat_span(V, nblk);
   const size_t beg = (size_t)b * span, end = beg + span < V ? beg + span : V;
-  const float mean = mean_invstd[c], invstd = mean_invstd[C + c];
+  const BnBwd k = bn_bwd_consts(mean_invstd, gamma, beta, pre, post, C, c);
   const float* __restrict__ xc = x + (size_t)c * V;
   const float* __restrict__ gc = dy + (size_t)c * V;
   double s = 0.0, q = 0.0;
@@ -128,12 +154,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { xv[k] = i + k < end ? xc[i + k] : 0.f; gv[k] = i + k < end ? gc[i + k] : 0.f; }
+      for (int j = 0; j < 4; ++j) { xv[j] = i + j < end ? xc[i + j] : 0.f; gv[j] = i + j < end ? gc[i + j] : 0.f; }
     }
     float ls = 0.f, lq = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (i + k < end) { ls += gv[k]; lq = fmaf(gv[k], (xv[k] - mean) * invstd, lq); }
+    for (int j = 0; j < 4; ++j)
+      if (i + j < end) {
+        float xh, g;
+        bn_bwd_elem(k, xv[j], gv[j], xh, g);
+        ls += g; lq = fmaf(g, xh, lq);
+      }
     s += ls; q += lq;
   }
   __shared__ double sh[8];
@@ -147,6 +177,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float pre, float post,
                                                            const double* __restrict__ partials, int nblk, int C, size_t V,
                                                            float* __restrict__ dx, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta) {
@@ -163,8 +194,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     if (threadIdx.x == 0) { tot[0] = s; tot[1] = q; }
   }
   __syncthreads();
-  const float mean = mean_invstd[c], invstd = mean_invstd[C + c];
-  const float a = (gamma ? gamma[c] : 1.f) * invstd;
+  const BnBwd k = bn_bwd_consts(mean_invstd, gamma, beta, pre, post, C, c);
   const float k1 = (float)(tot[0] / (double)V), k2 = (float)(tot[1] / (double)V);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (dgamma) dgamma[c] = (float)tot[1];
@@ -174,18 +204,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const float* __restrict__ gc = dy + (size_t)c * V;
   float* __restrict__ oc = dx + (size_t)c * V;
   const bool vec = (V & 3) == 0;
+  auto one = [&](float xv, float gv) {
+    float xh, g;
+    bn_bwd_elem(k, xv, gv, xh, g);
+    const float du = k.a * (g - k1 - xh * k2);
+    return (k.pre == 1.f || xv > 0.f) ? du : du * k.pre;
+  };
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < V; i += (size_t)gridDim.x * 1024) {
     if (vec) {
       const float4 f = *reinterpret_cast<const float4*>(xc + i);
       const float4 g = *reinterpret_cast<const float4*>(gc + i);
-      float4 o;
-      o.x = a * (g.x - k1 - (f.x - mean) * invstd * k2);
-      o.y = a * (g.y - k1 - (f.y - mean) * invstd * k2);
-      o.z = a * (g.z - k1 - (f.z - mean) * invstd * k2);
-      o.w = a * (g.w - k1 - (f.w - mean) * invstd * k2);
-      *reinterpret_cast<float4*>(oc + i) = o;
+      *reinterpret_cast<float4*>(oc + i) = make_float4(one(f.x, g.x), one(f.y, g.y), one(f.z, g.z), one(f.w, g.w));
     } else {
-      for (int k = 0; k < 4 && i + k < V; ++k) oc[i + k] = a * (gc[i + k] - k1 - (xc[i + k] - mean) * invstd * k2);
+      for (int j = 0; j < 4 && i + j < V; ++j) oc[i + j] = one(xc[i + j], gc[i + j]);
     }
   }
 }
@@ -352,10 +383,10 @@ extern "C" int dpi_channel_stats(const float* x, const float* chain, int C, size
 }
 
 extern "C" int dpi_bn_finalize(const double* partials, int nblk, int C, size_t count, const float* gamma, const float* beta,
-                               float eps, float momentum, float slope, float* running_mean, float* running_var,
+                               float eps, float momentum, float slope, int act_first, float* running_mean, float* running_var,
                                int64_t* num_batches_tracked, float* mean_invstd, float* chain_out, void* stream) {
   DPI_REQUIRE(partials && nblk > 0 && C > 0 && count > 0, "bn_finalize: bad argument");
-  bn_finalize_kernel<<<C, 64, 0, (hipStream_t)stream>>>(partials, nblk, C, (double)count, gamma, beta, eps, momentum, slope,
+  bn_finalize_kernel<<<C, 64, 0, (hipStream_t)stream>>>(partials, nblk, C, (double)count, gamma, beta, eps, momentum, slope, act_first,
                                                         running_mean, running_var, num_batches_tracked, mean_invstd, chain_out);
   return dpi_check_launch("bn_finalize");
 }
@@ -366,20 +397,22 @@ extern "C" int dpi_chain_apply(const float* x, const float* chain, int C, size_t
   return dpi_check_launch("chain_apply");
 }
 
-extern "C" int dpi_bn_bwd_reduce(const float* dy, const float* x, const float* mean_invstd, int C, size_t V, double* partials,
-                                 void* stream) {
+extern "C" int dpi_bn_bwd_reduce(const float* dy, const float* x, const float* mean_invstd, const float* gamma, const float* beta,
+                                 float pre_slope, float post_slope, int C, size_t V, double* partials, void* stream) {
   DPI_REQUIRE(dy && x && mean_invstd && partials && C > 0 && V > 0, "bn_bwd_reduce: bad argument");
   const int nblk = dpi_stat_blocks(C, V);
-  bn_bwd_reduce_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, C, V, nblk, partials);
+  bn_bwd_reduce_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, beta, pre_slope, post_slope, C, V,
+                                                                       nblk, partials);
   return dpi_check_launch("bn_bwd_reduce");
 }
 
-extern "C" int dpi_bn_bwd_apply(const float* dy, const float* x, const float* mean_invstd, const float* gamma,
-                                const double* partials, int nblk, int C, size_t V, float* dx, float* dgamma, float* dbeta,
-                                void* stream) {
+extern "C" int dpi_bn_bwd_apply(const float* dy, const float* x, const float* mean_invstd, const float* gamma, const float* beta,
+                                float pre_slope, float post_slope, const double* partials, int nblk, int C, size_t V, float* dx,
+                                float* dgamma, float* dbeta, void* stream) {
   DPI_REQUIRE(dy && x && mean_invstd && partials && dx && C > 0 && V > 0 && nblk > 0, "bn_bwd_apply: bad argument");
-  bn_bwd_apply_kernel<<<dim3(ew_blocks(cdivz(V, 4)), C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, partials, nblk,
-                                                                                      C, V, dx, dgamma, dbeta);
+  bn_bwd_apply_kernel<<<dim3(ew_blocks(cdivz(V, 4)), C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, beta, pre_slope,
+                                                                                      post_slope, partials, nblk, C, V, dx, dgamma,
+                                                                                      dbeta);
   return dpi_check_launch("bn_bwd_apply");
 }
 

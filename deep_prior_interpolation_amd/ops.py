@@ -118,20 +118,20 @@ def raw_channel_sum(x, C_, V, out):
 
 
 def raw_bn_stats_finalize(x, chain_in, C_, V, gamma, beta, slope, running_mean, running_var, nbt, mean_invstd, chain_out,
-                          eps=BN_EPS, momentum=BN_MOMENTUM):
+                          eps=BN_EPS, momentum=BN_MOMENTUM, act_first=0):
     """channel stats of T(x) followed by finalize."""
     L = _lib.load()
     nblk = L.dpi_stat_blocks(C_, V)
     part = torch.empty(nblk * C_ * 2, dtype=torch.float64, device=x.device)
     check(L.dpi_channel_stats(ptr(x), ptr(chain_in), C_, V, ptr(part), stream()), "dpi_channel_stats")
-    check(L.dpi_bn_finalize(ptr(part), nblk, C_, V, ptr(gamma), ptr(beta), eps, momentum, slope, ptr(running_mean),
+    check(L.dpi_bn_finalize(ptr(part), nblk, C_, V, ptr(gamma), ptr(beta), eps, momentum, slope, act_first, ptr(running_mean),
                             ptr(running_var), ptr(nbt), ptr(mean_invstd), ptr(chain_out), stream()), "dpi_bn_finalize")
 
 
 def raw_bn_finalize(part, nblk, C_, count, gamma, beta, slope, running_mean, running_var, nbt, mean_invstd, chain_out,
                     eps=BN_EPS, momentum=BN_MOMENTUM):
     L = _lib.load()
-    check(L.dpi_bn_finalize(ptr(part), nblk, C_, count, ptr(gamma), ptr(beta), eps, momentum, slope, ptr(running_mean),
+    check(L.dpi_bn_finalize(ptr(part), nblk, C_, count, ptr(gamma), ptr(beta), eps, momentum, slope, 0, ptr(running_mean),
                             ptr(running_var), ptr(nbt), ptr(mean_invstd), ptr(chain_out), stream()), "dpi_bn_finalize")
 
 
@@ -190,43 +190,99 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+def _bn_backward(dy, x, mi, gamma, beta, pre_slope, post_slope):
+    """two-phase BatchNorm backward with the surrounding LeakyReLU folded in; returns (dx, dgamma, dbeta)."""
+    L = _lib.load()
+    C_ = x.shape[1]
+    V = x.numel() // C_
+    nblk = L.dpi_stat_blocks(C_, V)
+    part = torch.empty(nblk * C_ * 2, dtype=torch.float64, device=x.device)
+    check(L.dpi_bn_bwd_reduce(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), pre_slope, post_slope, C_, V, ptr(part), stream()),
+          "dpi_bn_bwd_reduce")
+    dx = torch.empty_like(x)
+    dgamma = torch.empty_like(gamma)
+    dbeta = torch.empty_like(gamma)
+    check(L.dpi_bn_bwd_apply(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), pre_slope, post_slope, ptr(part), nblk, C_, V,
+                             ptr(dx), ptr(dgamma), ptr(dbeta), stream()), "dpi_bn_bwd_apply")
+    return dx, dgamma, dbeta
+
+
+def _pre_chain(C_, pre_slope, device):
+    return None if pre_slope == 1.0 else slope_chain(C_, pre_slope, device)
+
+
 class BatchNormFn(torch.autograd.Function):
-    """Train-mode BatchNorm over (D,H,W) of a single patch, optionally fused with LeakyReLU(slope)."""
+    """Train-mode BatchNorm over (D,H,W) of a single patch with optional fused LeakyReLU before (pre_slope: the
+    act -> BN tail of Block3d / ResPath3d) and/or after (post_slope: conv -> BN -> act).  Only the BN input is saved:
+    both activation masks are recomputed from it in the backward kernels."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, slope):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, post_slope, pre_slope=1.0):
         x = _req(x, "batchnorm input")
         C_ = x.shape[1]
         V = x.numel() // C_
         mi = torch.empty(2 * C_, dtype=torch.float32, device=x.device)
         chain = torch.empty(C_ * 5, dtype=torch.float32, device=x.device)
-        raw_bn_stats_finalize(x, None, C_, V, gamma, beta, slope, running_mean, running_var, nbt, mi, chain)
+        if pre_slope != 1.0 and post_slope != 1.0:
+            raise _lib.DpiError("batch_norm: pre and post activation cannot both be fused")
+        # act -> BN runs as ONE chained pass: statistics of act(x), then T(x) = (gamma*invstd) * act(x) + shift
+        raw_bn_stats_finalize(x, _pre_chain(C_, pre_slope, x.device), C_, V, gamma, beta,
+                              pre_slope if pre_slope != 1.0 else post_slope, running_mean, running_var, nbt, mi, chain,
+                              act_first=int(pre_slope != 1.0))
         y = torch.empty_like(x)
         raw_chain_apply(x, chain, C_, V, y)
-        ctx.save_for_backward(x, gamma, mi, y if slope != 1.0 else None)
-        ctx.slope = slope
+        ctx.save_for_backward(x, gamma, beta, mi)
+        ctx.slopes = (float(pre_slope), float(post_slope))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, mi, y = ctx.saved_tensors
+        x, gamma, beta, mi = ctx.saved_tensors
+        dx, dgamma, dbeta = _bn_backward(_req(dy, "batchnorm grad"), x, mi, gamma, beta, *ctx.slopes)
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class ConvBnActFn(torch.autograd.Function):
+    """conv -> BatchNorm(train) -> LeakyReLU(slope) in three launches: the conv's epilogue emits the {sum, sum^2}
+    partials, dpi_bn_finalize turns them into the per-channel chain, dpi_chain_apply writes the activation.
+    Backward: BN+act backward straight from (dy, raw conv output), then backward-data / backward-weight.
+    The conv bias feeds a BatchNorm, so its gradient is analytically zero and returned as zeros."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, stride, slope):
+        x, w = _req(x, "conv input"), _req(w, "conv weight")
+        d = make_desc(x, w, stride)
+        Do, Ho, Wo = desc_out_dims(d)
         L = _lib.load()
-        dy = _req(dy, "batchnorm grad")
-        C_ = x.shape[1]
-        V = x.numel() // C_
-        if ctx.slope != 1.0:
-            g = torch.empty_like(dy)
-            check(L.dpi_lrelu_bwd(ptr(dy), ptr(y), ctx.slope, dy.numel(), ptr(g), stream()), "dpi_lrelu_bwd")
-            dy = g
-        nblk = L.dpi_stat_blocks(C_, V)
-        part = torch.empty(nblk * C_ * 2, dtype=torch.float64, device=x.device)
-        check(L.dpi_bn_bwd_reduce(ptr(dy), ptr(x), ptr(mi), C_, V, ptr(part), stream()), "dpi_bn_bwd_reduce")
-        dx = torch.empty_like(x)
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(gamma)
-        check(L.dpi_bn_bwd_apply(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(part), nblk, C_, V, ptr(dx), ptr(dgamma),
-                                 ptr(dbeta), stream()), "dpi_bn_bwd_apply")
-        return dx, dgamma, dbeta, None, None, None, None
+        r = torch.empty(_like_spatial(x, d.Cout, Do, Ho, Wo), dtype=torch.float32, device=x.device)
+        nblk = L.dpi_conv_fwd_stat_blocks(C.byref(d))
+        part = torch.empty(nblk * d.Cout * 2, dtype=torch.float64, device=x.device)
+        raw_conv_fwd(d, x, None, w, b, r, part)
+        V = Do * Ho * Wo
+        mi = torch.empty(2 * d.Cout, dtype=torch.float32, device=x.device)
+        chain = torch.empty(d.Cout * 5, dtype=torch.float32, device=x.device)
+        raw_bn_finalize(part, nblk, d.Cout, V, gamma, beta, slope, running_mean, running_var, nbt, mi, chain)
+        y = torch.empty_like(r)
+        raw_chain_apply(r, chain, d.Cout, V, y)
+        ctx.save_for_backward(x, w, r, gamma, beta, mi)
+        ctx.d, ctx.slope, ctx.has_bias = d, float(slope), b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, r, gamma, beta, mi = ctx.saved_tensors
+        d = ctx.d
+        dr, dgamma, dbeta = _bn_backward(_req(dy, "conv-bn-act grad"), r, mi, gamma, beta, 1.0, ctx.slope)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            raw_conv_bwd_data(d, dr, w, dx)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            raw_conv_bwd_weight(d, x, None, dr, dw)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(d.Cout, dtype=torch.float32, device=x.device)
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None
 
 
 class LeakyReLUFn(torch.autograd.Function):
@@ -361,8 +417,12 @@ def conv(x, w, b, stride=1):
     return ConvFn.apply(x, w, b, stride)
 
 
-def batch_norm(x, gamma, beta, running_mean=None, running_var=None, nbt=None, slope=1.0):
-    return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, nbt, float(slope))
+def batch_norm(x, gamma, beta, running_mean=None, running_var=None, nbt=None, slope=1.0, pre_slope=1.0):
+    return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, nbt, float(slope), float(pre_slope))
+
+
+def conv_bn_act(x, w, b, gamma, beta, running_mean, running_var, nbt, stride=1, slope=0.2):
+    return ConvBnActFn.apply(x, w, b, gamma, beta, running_mean, running_var, nbt, int(stride), float(slope))
 
 
 def leaky_relu(x, slope=0.2):

@@ -87,22 +87,27 @@ int dpi_stat_blocks(int C, size_t V);
 /* partials[nblk][C][2] of T(x) over the V voxels of each channel */
 int dpi_channel_stats(const float* x, const float* chain, int C, size_t V, double* partials, void* stream);
 /* Reduce partials -> mean, invstd (biased var, eps); update running stats (momentum, unbiased var);
- * write chain_out[c] = {gamma*invstd, beta - mean*gamma*invstd, slope, 1, 0}  (i.e. BN-apply followed
- * by act with `slope`; slope = 1 means no activation).  running_* / nbt / chain_out may be NULL.
+ * write chain_out[c] = {gamma*invstd, beta - mean*gamma*invstd, slope, 1, 0}  (BN-apply followed by act with
+ * `slope`; slope = 1 means no activation) or, with act_first != 0, {1, 0, slope, gamma*invstd, beta - mean*...}
+ * (BN of act(x), the partials then being statistics of act(x)).  running_* / nbt / chain_out may be NULL.
  * mean_invstd: float[2][C]. */
 int dpi_bn_finalize(const double* partials, int nblk, int C, size_t count, const float* gamma,
-                    const float* beta, float eps, float momentum, float slope, float* running_mean,
-                    float* running_var, int64_t* num_batches_tracked, float* mean_invstd,
-                    float* chain_out, void* stream);
+                    const float* beta, float eps, float momentum, float slope, int act_first,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float* mean_invstd, float* chain_out, void* stream);
 /* y = T(x) elementwise */
 int dpi_chain_apply(const float* x, const float* chain, int C, size_t V, float* y, void* stream);
-/* BatchNorm backward, phase 1: partials[nblk][C][2] = {sum dy, sum dy*xhat}, xhat = (x-mean)*invstd */
-int dpi_bn_bwd_reduce(const float* dy, const float* x, const float* mean_invstd, int C, size_t V,
+/* BatchNorm backward, two-phase, with the surrounding LeakyReLU folded in (slope 1 = none):
+ *   pre_slope  (act -> BN, mulresunet.py:93-94,110-111): u = act(x) was normalised; dx = du * act'(x)
+ *   post_slope (BN -> act, base.py:214-215):            dy is w.r.t. act(BN(x)); g = dy * act'(gamma*xhat + beta)
+ * phase 1: partials[nblk][C][2] = {sum g, sum g*xhat}, xhat = (act_pre(x) - mean) * invstd
+ * phase 2: dx = gamma*invstd*(g - sum_g/V - xhat*sum_gxhat/V) * act_pre'(x); dgamma = sum_gxhat; dbeta = sum_g */
+int dpi_bn_bwd_reduce(const float* dy, const float* x, const float* mean_invstd, const float* gamma,
+                      const float* beta, float pre_slope, float post_slope, int C, size_t V,
                       double* partials, void* stream);
-/* phase 2: dx = gamma*invstd*(dy - sum_dy/V - xhat*sum_dyxhat/V); dgamma = sum_dyxhat; dbeta = sum_dy */
 int dpi_bn_bwd_apply(const float* dy, const float* x, const float* mean_invstd, const float* gamma,
-                     const double* partials, int nblk, int C, size_t V, float* dx, float* dgamma,
-                     float* dbeta, void* stream);
+                     const float* beta, float pre_slope, float post_slope, const double* partials,
+                     int nblk, int C, size_t V, float* dx, float* dgamma, float* dbeta, void* stream);
 /* dx = dy * act'(x) with act(v) = v>0 ? v : slope*v  (x = the activation INPUT or OUTPUT: same sign) */
 int dpi_lrelu_bwd(const float* dy, const float* x, float slope, size_t n, float* dx, void* stream);
 /* y = a + b */
