@@ -14,6 +14,15 @@ void dpi_conv_out_dims(const dpi_conv_desc* d, int* Do, int* Ho, int* Wo);
 size_t dpi_conv_bwd_weight_mfma_ws_floats(const dpi_conv_desc* d);
 int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws,
                                  hipStream_t st);
+size_t dpi_conv_pw_bwd_weight_mfma_ws_floats(const dpi_conv_desc* d);
+int dpi_conv_pw_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws,
+                                    hipStream_t st);
+size_t dpi_conv_bwd_weight_smallco_ws_floats(const dpi_conv_desc* d);
+int dpi_conv_bwd_weight_smallco_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws,
+                                    hipStream_t st);
+static bool bw_use_smallco(const dpi_conv_desc* d) {
+  return d->k == 3 && d->kd == 3 && d->stride == 1 && d->Cout <= 5 && (size_t)d->D * d->H * d->W >= 32768;
+}
 static int g_bw_mfma_min_cout = 8;
 extern "C" void dpi_set_bwd_weight_mfma_min_cout(int n) { g_bw_mfma_min_cout = n; }
 static bool bw_use_mfma(const dpi_conv_desc* d) { return d->k == 3 && d->Cout >= g_bw_mfma_min_cout; }
@@ -269,6 +278,8 @@ BwPlan plan(const dpi_conv_desc* d) {
 extern "C" size_t dpi_conv_bwd_weight_ws_floats(const dpi_conv_desc* d) {
   if (!d || d->Cin <= 0 || d->Cout <= 0) return 0;
   if (bw_use_mfma(d)) return dpi_conv_bwd_weight_mfma_ws_floats(d);
+  if (bw_use_smallco(d)) return dpi_conv_bwd_weight_smallco_ws_floats(d);
+  if (d->k == 1 && d->Cout >= g_bw_mfma_min_cout) return dpi_conv_pw_bwd_weight_mfma_ws_floats(d);
   const BwPlan p = plan(d);
   return (size_t)p.nchunks * d->Cout * d->Cin * d->kd * d->k * d->k;
 }
@@ -285,6 +296,20 @@ extern "C" int dpi_conv_bwd_weight(const dpi_conv_desc* d, const float* x, const
       return DPI_E_WORKSPACE;
     }
     return dpi_conv_bwd_weight_mfma_run(d, x, x_chain, dy, dw, ws, st);
+  }
+  if (bw_use_smallco(d)) {
+    if (ws_floats < dpi_conv_bwd_weight_smallco_ws_floats(d)) {
+      dpi_set_error("conv_bwd_weight: workspace %zu < %zu floats", ws_floats, dpi_conv_bwd_weight_smallco_ws_floats(d));
+      return DPI_E_WORKSPACE;
+    }
+    return dpi_conv_bwd_weight_smallco_run(d, x, x_chain, dy, dw, ws, st);
+  }
+  if (d->k == 1 && d->Cout >= g_bw_mfma_min_cout) {
+    if (ws_floats < dpi_conv_pw_bwd_weight_mfma_ws_floats(d)) {
+      dpi_set_error("conv_bwd_weight: workspace %zu < %zu floats", ws_floats, dpi_conv_pw_bwd_weight_mfma_ws_floats(d));
+      return DPI_E_WORKSPACE;
+    }
+    return dpi_conv_pw_bwd_weight_mfma_run(d, x, x_chain, dy, dw, ws, st);
   }
   const BwPlan p = plan(d);
   const size_t per = (size_t)d->Cout * d->Cin * d->kd * d->k * d->k;

@@ -436,6 +436,8 @@ int check_desc(const dpi_conv_desc* d) {
 // MFMA stencil path (conv_mfma.hip): k = 3, stride 1, enough output channels to fill a 16-row MFMA tile
 int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
                       double* partials, bool flip, int accumulate, hipStream_t st);
+int dpi_conv_pw_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
+                         double* partials, bool flip, int accumulate, hipStream_t st);
 int dpi_conv_bwd_data_s2_mfma_run(const dpi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, hipStream_t st);
 void dpi_mfma_variant(const dpi_conv_desc* d, int cout, int* nr, int* nh);
 int dpi_mfma_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth, int* ntw);
@@ -474,6 +476,7 @@ static int conv_run(const dpi_conv_desc* d, const float* x, const float* chain, 
   const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
   if (d->k == 3 && cout >= g_mfma_min_cout && (d->stride == 1 || !flip))
     return dpi_conv_mfma_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
+  if (d->k == 1 && cout >= g_mfma_min_cout) return dpi_conv_pw_mfma_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
   const int co_b = pick_co_b(cout);
   if (d->k == 1) {
     PwArgs a{x, chain, w, bias, y, partials, cin, cout, (size_t)Do * Ho * Wo, w_out, w_in, accumulate};

@@ -350,6 +350,140 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- backward-weight, few output channels ---------------
+// With Cout <= 5 the [co x tap] MFMA tile above is three-quarters empty.  Move the kw shift to the dy side instead:
+//     dW[co][ci][kd][kh][kw] = sum_{d,h,u} X'[ci][d+kd-1][h+kh-1][u] * dy[co][d][h][u - kw]      (u = input column)
+//     D[(ci,kd,kh) 16][(co,kw) 16] += A[(ci,kd,kh)][u 4] * B[u 4][(co,kw)]
+// A = halo tile in LDS (6 input channels x 9 (kd,kh) = 54 of 64 rows over 4 MFMA tiles; per-lane row offsets),
+// B = dy read straight from global memory (lane: u = 4s + (l>>4), co = (l&15)/3, kw = (l&15)%3; 3*Cout of 16 columns).
+// One B value feeds 4 MFMAs.  3-D, stride 1 only (the three full-resolution layers this exists for).
+struct BwSArgs {
+  const float* __restrict__ x;
+  const float* __restrict__ chain;
+  const float* __restrict__ dy;
+  float* __restrict__ ws;   // [nchunks][Cout][Cin][27]
+  int Cin, Cout;
+  int D, H, W;
+  int ntd, nth, ntw, ntiles, tiles_per_chunk;
+};
+
+__global__ __launch_bounds__(256) void conv_bwd_weight_smallco_kernel(BwSArgs a) {
+  constexpr int CB = 6;                                  // input channels per block
+  constexpr int TZ = 4, TY = 8, ID = 6, IH = 10, IW = 34, RS = 36;
+  constexpr int CS0 = ID * IH * RS;                      // 2160
+  constexpr int CS = CS0 + 2;                            // = 18 (mod 32): rows of one lane group land on distinct banks mostly
+  constexpr int TILE = ID * IH * RS;                     // the 2 pad columns of every row are staged too (as zeros): the
+  constexpr int E = (TILE + 255) / 256;                  // 9th k-step reads them, and 0 * stale-LDS-NaN would poison the sum
+  __shared__ __attribute__((aligned(16))) float lds[CB * CS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int c0 = blockIdx.y * CB;
+  const size_t V = (size_t)a.D * a.H * a.W;
+
+  // A-operand row of this lane in each of the 4 M tiles: q = 16 t + lj -> (channel q/9, kd, kh)
+  int aoff[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int q = 16 * t + lj;
+    if (q >= CB * 9) q = CB * 9 - 1;                     // unused rows: any valid address
+    const int cl = q / 9, kd = (q % 9) / 3, kh = q % 3;
+    aoff[t] = cl * CS + (kd * IH + kh) * RS;
+  }
+  const int bco = lj / 3, bkw = lj % 3;
+  const bool bok = bco < a.Cout && lj < 15;
+  const float* __restrict__ dyc = a.dy + (size_t)(bok ? bco : 0) * V;
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int t_begin = blockIdx.x * a.tiles_per_chunk;
+  const int t_end = min(t_begin + a.tiles_per_chunk, a.ntiles);
+  int goff[E], loff[E];
+  float sr[CB][E];
+  auto slots = [&](int tile, int& od0, int& oh0, int& ow0) {
+    int bt = tile;
+    const int tw_i = bt % a.ntw; bt /= a.ntw;
+    const int th_i = bt % a.nth; bt /= a.nth;
+    od0 = bt * TZ; oh0 = th_i * TY; ow0 = tw_i * 32;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int idx = tid + e * 256;
+      const int col = idx % RS, row = idx / RS;
+      const int hy = row % IH, dz = row / IH;
+      const int gd = od0 - 1 + dz, gh = oh0 - 1 + hy, gw = ow0 - 1 + col;
+      const bool ok = idx < TILE && col < IW && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+      goff[e] = ok ? (gd * a.H + gh) * a.W + gw : -1;
+      loff[e] = idx < TILE ? (dz * IH + hy) * RS + col : -1;
+    }
+  };
+  auto gload = [&]() {
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const int ci = c0 + c;
+      const bool cok = ci < a.Cin;
+      const float* __restrict__ xc = a.x + (size_t)(cok ? ci : 0) * V;
+#pragma unroll
+      for (int e = 0; e < E; ++e) sr[c][e] = (cok && goff[e] >= 0) ? xc[goff[e]] : 0.f;
+    }
+  };
+  int od0 = 0, oh0 = 0, ow0 = 0;
+  if (t_begin < t_end) { slots(t_begin, od0, oh0, ow0); gload(); }
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const int ci = c0 + c;
+      const Chain t = load_chain(a.chain, ci < a.Cin ? ci : 0);
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (loff[e] >= 0) lds[c * CS + loff[e]] = (a.chain && goff[e] >= 0 && ci < a.Cin) ? apply_chain(t, sr[c][e]) : sr[c][e];
+    }
+    __syncthreads();
+    const int cod = od0 + wid, coh0 = oh0, cow0 = ow0;
+    if (tile + 1 < t_end) { slots(tile + 1, od0, oh0, ow0); gload(); }
+    const int lrow = (wid * IH) * RS + lk;               // this wave's depth slice, column 4s + lk added below
+#pragma unroll 2
+    for (int hr = 0; hr < TY; ++hr) {
+      const int oh = coh0 + hr;
+      const bool row_ok = bok && cod < a.D && oh < a.H;
+      const size_t rbase = ((size_t)cod * a.H + oh) * a.W;
+      float g[9];
+#pragma unroll
+      for (int s = 0; s < 9; ++s) {
+        const int ul = 4 * s + lk - bkw;                 // output column (tile-local) paired with input column 4s + lk
+        const int ow = cow0 + ul;
+        g[s] = (row_ok && ul >= 0 && ul < 32 && ow < a.W) ? dyc[rbase + ow] : 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < 9; ++s) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float av = lds[aoff[t] + lrow + hr * RS + 4 * s];
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, g[s], acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- cross-wave reduction, one partial per (chunk, co, ci, tap): D row q = 16t + 4*lk + r, col = (co, kw) ------------
+  __syncthreads();
+  float* red = lds;   // [4 waves][4 t][4 r][64 lanes]
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((wid * 4 + t) * 4 + r) * 64 + lane] = acc[t][r];
+  __syncthreads();
+  for (int e = tid; e < 4 * 4 * 64; e += 256) {
+    const int l = e & 63, r = (e >> 6) & 3, t = e >> 8;
+    const float sum = red[e] + red[e + 1024] + red[e + 2048] + red[e + 3072];
+    const int q = 16 * t + 4 * (l >> 4) + r, j = l & 15;
+    const int cl = q / 9, kd = (q % 9) / 3, kh = q % 3, co = j / 3, kw = j % 3, ci = c0 + cl;
+    if (q < CB * 9 && j < 15 && co < a.Cout && ci < a.Cin)
+      a.ws[(((size_t)blockIdx.x * a.Cout + co) * a.Cin + ci) * 27 + (kd * 3 + kh) * 3 + kw] = sum;
+  }
+}
+
 // ---------------------------------------------------------------- backward-data, stride 2 ---------------------------
 // dx[ci][i] = sum_co sum_k dy[co][(i + 1 - k) / 2] * w[co][ci][k]   (per axis; only integer quotients contribute).
 // Writing i = 2m + p: p = 0 uses tap k = 1 at o = m; p = 1 uses k = 2 at o = m and k = 0 at o = m + 1.  Each of the
@@ -585,4 +719,34 @@ int dpi_conv_bwd_data_s2_mfma_run(const dpi_conv_desc* d, const float* dy, const
   if (d->kd == 3) conv_bwd_data_s2_mfma_kernel<3><<<grid, 256, 0, st>>>(a);
   else conv_bwd_data_s2_mfma_kernel<1><<<grid, 256, 0, st>>>(a);
   return dpi_check_launch("conv_bwd_data_s2_mfma");
+}
+
+// few-output-channel backward-weight (3-D, stride 1, Cout <= 5)
+struct SmallBwPlan { int nchunks, tiles_per_chunk, ntiles, ntd, nth, ntw; };
+static SmallBwPlan small_bw_plan(const dpi_conv_desc* d) {
+  SmallBwPlan p{};
+  p.ntd = cdiv(d->D, 4); p.nth = cdiv(d->H, 8); p.ntw = cdiv(d->W, 32);
+  p.ntiles = p.ntd * p.nth * p.ntw;
+  const size_t per = (size_t)d->Cout * d->Cin * 27;
+  const size_t max_chunks_mem = per ? ((size_t)32 << 20) / per : 1;
+  size_t want = cdivz(1024, (size_t)cdiv(d->Cin, 6));
+  if (want > (size_t)p.ntiles) want = p.ntiles;
+  if (want > max_chunks_mem) want = max_chunks_mem;
+  if (want < 1) want = 1;
+  p.tiles_per_chunk = (int)cdivz(p.ntiles, want);
+  p.nchunks = cdiv(p.ntiles, p.tiles_per_chunk);
+  return p;
+}
+size_t dpi_conv_bwd_weight_smallco_ws_floats(const dpi_conv_desc* d) {
+  return (size_t)small_bw_plan(d).nchunks * d->Cout * d->Cin * 27;
+}
+int dpi_conv_bwd_weight_smallco_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws,
+                                    hipStream_t st) {
+  const SmallBwPlan p = small_bw_plan(d);
+  BwSArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk};
+  conv_bwd_weight_smallco_kernel<<<dim3(p.nchunks, cdiv(d->Cin, 6)), 256, 0, st>>>(a);
+  if (int e = dpi_check_launch("conv_bwd_weight_smallco")) return e;
+  const size_t per = (size_t)d->Cout * d->Cin * 27;
+  reduce_chunks2_kernel<<<(unsigned)cdivz(per * 8, 256), 256, 0, st>>>(ws, dw, per, p.nchunks);
+  return dpi_check_launch("reduce_chunks");
 }

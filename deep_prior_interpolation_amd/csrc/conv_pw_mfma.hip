@@ -1,0 +1,281 @@
+// 1x1x1 convolutions (channel GEMMs) on fp32 MFMA: forward / backward-data and backward-weight.
+//
+// These are the only true channel x channel GEMMs of the network (Block3d.shortcut, ResPath3d.conv1x1;
+// reference mulresunet.py:72,103) and they are HBM-bound (AI ~ 10 FLOP/B): every activation is read once as
+// float4 and each MFMA tile is fed straight from those registers, no LDS staging.
+//
+//   forward:   D[co 16][vox 16] += A[co][ci 4] * B[ci 4][vox 16]
+//              lane (lk = l>>4, lj = l&15) loads float4 x[c0+lk][v0 + 4*lj .. +3]; element e of the float4 is column lj of
+//              voxel tile e, so 4 MFMAs consume one load and the epilogue stores float4 y[co][v0 + 4*lj .. +3].
+//   bwd-weight: D[co 16][ci 16] += A[co][vox 4] * B[vox 4][ci]
+//              lane loads float4 dy[co = lj][v0 + 4*lk .. +3] and x[ci = lj][v0 + 4*lk .. +3]; element e pairs the voxels
+//              {v0 + 4*lk + e} of both operands.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct PwMArgs {
+  const float* __restrict__ x;
+  const float* __restrict__ chain;
+  const float* __restrict__ w;
+  const float* __restrict__ bias;
+  float* __restrict__ y;
+  double* __restrict__ partials;
+  int Cin, Cout;
+  size_t V;
+  long w_out_stride, w_in_stride;
+  int accumulate;
+};
+
+// block = 4 waves = 1024 voxels (wave w takes 64-voxel groups w, w+4, w+8, w+12); MT cout tiles per block
+template <int MT>
+__global__ __launch_bounds__(256) void conv_pw_mfma_kernel(PwMArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int n0 = blockIdx.y * 16 * MT;
+  const bool vec = (a.V & 3) == 0;
+  double ssum[MT][4], qsum[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[m][r] = 0.0; qsum[m][r] = 0.0; }
+
+  for (int grp = wid; grp < 16; grp += 4) {
+    const size_t v0 = (size_t)blockIdx.x * 1024 + (size_t)grp * 64 + 4 * lj;
+    if ((size_t)blockIdx.x * 1024 + (size_t)grp * 64 >= a.V) break;
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[m][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < a.Cin; c0 += 4) {
+      const int ci = c0 + lk;
+      const bool cok = ci < a.Cin;
+      float b[4] = {0.f, 0.f, 0.f, 0.f};
+      if (cok) {
+        const float* __restrict__ xp = a.x + (size_t)ci * a.V + v0;
+        if (vec && v0 + 3 < a.V) {
+          const float4 f = *reinterpret_cast<const float4*>(xp);
+          b[0] = f.x; b[1] = f.y; b[2] = f.z; b[3] = f.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[e] = v0 + e < a.V ? xp[e] : 0.f;
+        }
+        if (a.chain) {
+          const Chain t = load_chain(a.chain, ci);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[e] = apply_chain(t, b[e]);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int co = n0 + m * 16 + lj;
+        const float wv = (cok && co < a.Cout) ? a.w[co * a.w_out_stride + ci * a.w_in_stride] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[m][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, b[e], acc[m][e], 0, 0, 0);
+      }
+    }
+    // D row = co (4*lk + r), D col lj of tile e = voxel v0 + e
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = n0 + m * 16 + 4 * lk + r;
+        if (co < a.Cout) {
+          const float bv = a.bias ? a.bias[co] : 0.f;
+          float* yp = a.y + (size_t)co * a.V + v0;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[m][e][r] + bv;
+          if (vec && v0 + 3 < a.V) {
+            if (a.accumulate) {
+              const float4 o = *reinterpret_cast<const float4*>(yp);
+              v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+            }
+            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ssum[m][r] += v[e]; qsum[m][r] += (double)v[e] * v[e]; }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (v0 + e < a.V) {
+                if (a.accumulate) v[e] += yp[e];
+                yp[e] = v[e];
+                ssum[m][r] += v[e]; qsum[m][r] += (double)v[e] * v[e];
+              }
+          }
+        }
+      }
+  }
+  if (a.partials) {
+    __shared__ double red[4][16 * MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double s = ssum[m][r], q = qsum[m][r];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if (lj == 0) { red[wid][m * 16 + 4 * lk + r][0] = s; red[wid][m * 16 + 4 * lk + r][1] = q; }
+      }
+    __syncthreads();
+    if (tid < 32 * MT) {
+      const int c = tid >> 1, which = tid & 1;
+      const double rs = red[0][c][which] + red[1][c][which] + red[2][c][which] + red[3][c][which];
+      if (n0 + c < a.Cout) a.partials[((size_t)blockIdx.x * a.Cout + n0 + c) * 2 + which] = rs;
+    }
+  }
+}
+
+// ---- backward-weight ---------------------------------------------------------------------------------------------
+struct PwBwArgs {
+  const float* __restrict__ x;
+  const float* __restrict__ chain;
+  const float* __restrict__ dy;
+  float* __restrict__ ws;   // [nchunks][Cout][Cin]
+  int Cin, Cout;
+  size_t V;
+  size_t vox_per_chunk;     // multiple of 64
+};
+
+template <int MT, int NT>   // MT cout tiles x NT cin tiles per block
+__global__ __launch_bounds__(256) void conv_pw_bwd_weight_mfma_kernel(PwBwArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int ci0 = blockIdx.y * 16 * NT, co0 = blockIdx.z * 16 * MT;
+  const bool vec = (a.V & 3) == 0;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  Chain ch[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) ch[n] = load_chain(a.chain, min(ci0 + n * 16 + lj, a.Cin - 1));
+
+  const size_t vbeg = (size_t)blockIdx.x * a.vox_per_chunk;
+  const size_t vend = vbeg + a.vox_per_chunk < a.V ? vbeg + a.vox_per_chunk : a.V;
+  for (size_t g0 = vbeg + (size_t)wid * 16; g0 < vend; g0 += 64) {
+    const size_t v0 = g0 + 4 * lk;
+    float ga[MT][4], xb[NT][4];
+    auto load4 = [&](const float* __restrict__ p, float (&o)[4]) {
+      if (vec && v0 + 3 < vend) {
+        const float4 f = *reinterpret_cast<const float4*>(p);
+        o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = f.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v0 + e < vend ? p[e] : 0.f;
+      }
+    };
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int co = co0 + m * 16 + lj;
+      if (co < a.Cout) load4(a.dy + (size_t)co * a.V + v0, ga[m]);
+      else { ga[m][0] = ga[m][1] = ga[m][2] = ga[m][3] = 0.f; }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int ci = ci0 + n * 16 + lj;
+      if (ci < a.Cin) {
+        load4(a.x + (size_t)ci * a.V + v0, xb[n]);
+        if (a.chain) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xb[n][e] = (v0 + e < vend) ? apply_chain(ch[n], xb[n][e]) : 0.f;
+        }
+      } else { xb[n][0] = xb[n][1] = xb[n][2] = xb[n][3] = 0.f; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[m][e], xb[n][e], acc[m][n], 0, 0, 0);
+  }
+  // cross-wave reduction; D row = co (4*lk + r), col = ci lj
+  __shared__ float red[4][MT * NT * 4 * 64];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wid][((m * NT + n) * 4 + r) * 64 + lane] = acc[m][n][r];
+  __syncthreads();
+  for (int e = tid; e < MT * NT * 4 * 64; e += 256) {
+    const int l = e & 63, r = (e >> 6) & 3, n = (e >> 8) % NT, m = (e >> 8) / NT;
+    const int co = co0 + m * 16 + 4 * (l >> 4) + r, ci = ci0 + n * 16 + (l & 15);
+    if (co < a.Cout && ci < a.Cin)
+      a.ws[((size_t)blockIdx.x * a.Cout + co) * a.Cin + ci] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+  }
+}
+
+__global__ void reduce_chunks_pw_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n, int nchunks) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = gid >> 3;
+  const int part = gid & 7;
+  float s = 0.f;
+  if (i < n)
+    for (int c = part; c < nchunks; c += 8) s += ws[(size_t)c * n + i];
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  if (i < n && part == 0) out[i] = s;
+}
+
+struct PwBwPlan { int nchunks; size_t vox_per_chunk; int mt, nt; };
+PwBwPlan pw_bw_plan(const dpi_conv_desc* d) {
+  PwBwPlan p{};
+  const size_t V = (size_t)d->D * d->H * d->W;
+  p.mt = d->Cout > 16 ? 2 : 1;
+  p.nt = d->Cin > 32 ? 4 : (d->Cin > 16 ? 2 : 1);
+  const size_t blocks_other = (size_t)cdiv(d->Cin, 16 * p.nt) * cdiv(d->Cout, 16 * p.mt);
+  const size_t units = cdivz(V, 64);
+  const size_t per = (size_t)d->Cout * d->Cin;
+  const size_t max_chunks_mem = per ? ((size_t)32 << 20) / per : 1;
+  size_t want = cdivz(1024, blocks_other);
+  if (want > units) want = units;
+  if (want > max_chunks_mem) want = max_chunks_mem;
+  if (want < 1) want = 1;
+  const size_t upc = cdivz(units, want);
+  p.vox_per_chunk = upc * 64;
+  p.nchunks = (int)cdivz(units, upc);
+  return p;
+}
+
+}  // namespace
+
+int dpi_conv_pw_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
+                         double* partials, bool flip, int accumulate, hipStream_t st) {
+  const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
+  const long w_out = flip ? 1 : (long)d->Cin, w_in = flip ? (long)d->Cin : 1;
+  PwMArgs a{x, chain, w, bias, y, partials, cin, cout, (size_t)d->D * d->H * d->W, w_out, w_in, accumulate};
+  const unsigned gx = (unsigned)cdivz(a.V, 1024);
+  if (cout <= 16) conv_pw_mfma_kernel<1><<<dim3(gx, 1), 256, 0, st>>>(a);
+  else if (cout <= 32) conv_pw_mfma_kernel<2><<<dim3(gx, 1), 256, 0, st>>>(a);
+  else conv_pw_mfma_kernel<4><<<dim3(gx, cdiv(cout, 64)), 256, 0, st>>>(a);
+  return dpi_check_launch("conv_pw_mfma");
+}
+
+size_t dpi_conv_pw_bwd_weight_mfma_ws_floats(const dpi_conv_desc* d) {
+  const PwBwPlan p = pw_bw_plan(d);
+  return (size_t)p.nchunks * d->Cout * d->Cin;
+}
+
+int dpi_conv_pw_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws,
+                                    hipStream_t st) {
+  const PwBwPlan p = pw_bw_plan(d);
+  PwBwArgs a{x, chain, dy, ws, d->Cin, d->Cout, (size_t)d->D * d->H * d->W, p.vox_per_chunk};
+  dim3 grid(p.nchunks, cdiv(d->Cin, 16 * p.nt), cdiv(d->Cout, 16 * p.mt));
+  if (p.mt == 1) {
+    if (p.nt == 1) conv_pw_bwd_weight_mfma_kernel<1, 1><<<grid, 256, 0, st>>>(a);
+    else if (p.nt == 2) conv_pw_bwd_weight_mfma_kernel<1, 2><<<grid, 256, 0, st>>>(a);
+    else conv_pw_bwd_weight_mfma_kernel<1, 4><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (p.nt == 1) conv_pw_bwd_weight_mfma_kernel<2, 1><<<grid, 256, 0, st>>>(a);
+    else if (p.nt == 2) conv_pw_bwd_weight_mfma_kernel<2, 2><<<grid, 256, 0, st>>>(a);
+    else conv_pw_bwd_weight_mfma_kernel<2, 4><<<grid, 256, 0, st>>>(a);
+  }
+  if (int e = dpi_check_launch("conv_pw_bwd_weight_mfma")) return e;
+  const size_t per = (size_t)d->Cout * d->Cin;
+  reduce_chunks_pw_kernel<<<(unsigned)cdivz(per * 8, 256), 256, 0, st>>>(ws, dw, per, p.nchunks);
+  return dpi_check_launch("reduce_chunks_pw");
+}

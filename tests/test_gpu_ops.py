@@ -64,6 +64,8 @@ CONV_RANDOM = [
     # MFMA paths: small-tile variants (few voxels), stride 2 with >= 8 channels, odd sizes, channel tails
     (12, 9, (7, 9, 11), 3, 2), (9, 20, (8, 8, 40), 3, 2), (105, 64, (4, 8, 16), 3, 1), (17, 26, (6, 6, 6), 3, 1),
     (16, 16, (3, 5, 17), 3, 1), (9, 33, (12, 16, 64), 3, 1), (212, 212, (2, 2, 2), 3, 2),
+    # few-output-channel backward-weight MFMA kernel (Cout <= 5, >= 32768 voxels), channel / size tails
+    (13, 4, (32, 32, 40), 3, 1), (7, 1, (33, 31, 37), 3, 1), (6, 5, (32, 32, 32), 3, 1), (64, 4, (16, 48, 64), 3, 1),
 ]
 
 
@@ -73,10 +75,11 @@ def test_conv_vs_oracle(ops, cin, cout, shape, k, stride):
     x = torch.randn((1, cin) + shape, generator=gen)
     w = torch.randn((cout, cin, k, k, k), generator=gen) * (1.0 / np.sqrt(cin * k ** 3))
     b = torch.randn(cout, generator=gen)
-    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    # fp64 oracle: only the GPU's own fp32 rounding is measured (an fp32 CPU reference is itself ~1e-6 off, box-dependent)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
     yr = O.conv_nd(xr, wr, br, stride)
     dy = torch.randn(yr.shape, generator=gen)
-    yr.backward(dy)
+    yr.backward(dy.double())
     xg, wg, bg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
     y = ops.conv(xg, wg, bg, stride)
     assert rel(y, yr) < 2e-6
@@ -94,10 +97,10 @@ def test_conv2d_vs_oracle(ops, cin, cout, shape, k, stride):
     x = torch.randn((1, cin) + shape[1:], generator=gen)
     w = torch.randn((cout, cin, k, k), generator=gen) * 0.2
     b = torch.randn(cout, generator=gen)
-    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
     yr = O.conv_nd(xr, wr, br, stride)
     dy = torch.randn(yr.shape, generator=gen)
-    yr.backward(dy)
+    yr.backward(dy.double())
     xg, wg, bg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
     y = ops.conv(xg, wg, bg, stride)
     assert rel(y, yr) < 2e-6
