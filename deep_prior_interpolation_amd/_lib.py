@@ -59,6 +59,8 @@ SIGNATURES = {
     "dpi_loss_ws_doubles": (_Z, [_Z]),
     "dpi_masked_loss": (_I, [_P, _P, _P, _Z, _I, _F, _P, _P, _P, _P]),
     "dpi_adam_multi": (_I, [_P, _P, _I, _P, C.c_double, C.c_double, C.c_double, _P, _P]),
+    "dpi_loop_control": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, C.c_double, C.c_double, _I, C.c_double, C.c_double, _I, C.c_double, _P]),
+    "dpi_copy_if": (_I, [_P, _P, _P, _Z, _P]),
     "dpi_noise_add": (_I, [_P, _Z, _F, _U64, _P, _P, _P]),
     "dpi_fill_normal": (_I, [_P, _Z, _F, _F, _U64, _U64, _P]),
     "dpi_overlap_add": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P]),

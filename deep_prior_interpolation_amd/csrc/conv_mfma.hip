@@ -308,17 +308,21 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
       tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
       stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
     }
-#pragma unroll 2
-    for (int hr = 0; hr < NR; ++hr) {
+    auto load_g = [&](float (&g)[KS], int hr) {
       const int oh = coh0 + hr;
       const bool row_ok = co_ok && cod < Do && oh < Ho;
       const size_t rbase = ((size_t)cod * Ho + oh) * Wo;
-      float g[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const int ow = cow0 + 4 * s + lk;
         g[s] = (row_ok && ow < Wo) ? dyc[rbase + ow] : 0.f;
       }
+    };
+    float g[KS], gn[KS];
+    load_g(g, 0);
+#pragma unroll
+    for (int hr = 0; hr < NR; ++hr) {
+      if (hr + 1 < NR) load_g(gn, hr + 1);               // next row's dy behind this row's MFMAs
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -329,6 +333,8 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
             acc[c][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[s], b, acc[c][tt], 0, 0, 0);
           }
       }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) g[s] = gn[s];
     }
   }
   // ---- cross-wave reduction through LDS, then one partial per (chunk, co, ci, tap) ------------------------------------
@@ -444,18 +450,22 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_smallco_kernel(BwSArgs a)
     const int cod = od0 + wid, coh0 = oh0, cow0 = ow0;
     if (tile + 1 < t_end) { slots(tile + 1, od0, oh0, ow0); gload(); }
     const int lrow = (wid * IH) * RS + lk;               // this wave's depth slice, column 4s + lk added below
-#pragma unroll 2
-    for (int hr = 0; hr < TY; ++hr) {
+    auto load_g = [&](float (&g)[9], int hr) {
       const int oh = coh0 + hr;
       const bool row_ok = bok && cod < a.D && oh < a.H;
       const size_t rbase = ((size_t)cod * a.H + oh) * a.W;
-      float g[9];
 #pragma unroll
       for (int s = 0; s < 9; ++s) {
         const int ul = 4 * s + lk - bkw;                 // output column (tile-local) paired with input column 4s + lk
         const int ow = cow0 + ul;
         g[s] = (row_ok && ul >= 0 && ul < 32 && ow < a.W) ? dyc[rbase + ow] : 0.f;
       }
+    };
+    float g[9], gn[9];
+    load_g(g, 0);
+#pragma unroll
+    for (int hr = 0; hr < TY; ++hr) {
+      if (hr + 1 < TY) load_g(gn, hr + 1);               // next row's dy behind this row's MFMAs
 #pragma unroll
       for (int s = 0; s < 9; ++s) {
 #pragma unroll
@@ -464,6 +474,8 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_smallco_kernel(BwSArgs a)
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, g[s], acc[t], 0, 0, 0);
         }
       }
+#pragma unroll
+      for (int s = 0; s < 9; ++s) g[s] = gn[s];
     }
   }
   // ---- cross-wave reduction, one partial per (chunk, co, ci, tap): D row q = 16t + 4*lk + r, col = (co, kw) ------------

@@ -153,6 +153,47 @@ __global__ __launch_bounds__(256) void overlap_norm_kernel(float* __restrict__ a
   }
 }
 
+// ---- device-resident loop control (one thread): history row, best-output flag, ReduceLROnPlateau, EarlyStopping ---------
+// state (double[8]): {iter, loss_min, plateau_best, plateau_bad, es_best, es_bad, es_has_best, reserved}
+__global__ void loop_control_kernel(const double* __restrict__ metrics, double* __restrict__ state, double* __restrict__ hist,
+                                    int max_iters, float* __restrict__ step_lr, int* __restrict__ active, int* __restrict__ improved,
+                                    int use_plateau, double factor, double threshold, int patience, double min_lr, double lr_eps,
+                                    int es_patience, double es_min_delta) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  *improved = 0;
+  if (!*active) return;
+  const int it = (int)state[0];
+  const double loss = metrics[0];
+  const double lr = (double)step_lr[1];
+  if (it < max_iters) { hist[4 * it + 0] = loss; hist[4 * it + 1] = metrics[1]; hist[4 * it + 2] = metrics[2]; hist[4 * it + 3] = lr; }
+  if (it == 0 || loss <= state[1]) { state[1] = loss; *improved = 1; }                     // main.py:173-180
+  if (use_plateau) {                                                                        // torch ReduceLROnPlateau, mode min / rel
+    if (loss < state[2] * (1.0 - threshold)) { state[2] = loss; state[3] = 0.0; }
+    else state[3] += 1.0;
+    if (state[3] > (double)patience) {
+      const double nl = fmax(lr * factor, min_lr);
+      if (lr - nl > lr_eps) step_lr[1] = (float)nl;
+      state[3] = 0.0;
+    }
+  }
+  if (es_patience != 0) {                                                                   // utils/torch.py:216-275, percentage mode
+    if (state[6] == 0.0) { state[4] = loss; state[6] = 1.0; }
+    else if (loss != loss) *active = 0;                                                     // NaN loss stops immediately
+    else {
+      if (loss < state[4] - state[4] * es_min_delta / 100.0) { state[5] = 0.0; state[4] = loss; }
+      else state[5] += 1.0;
+      if (state[5] >= (double)es_patience) *active = 0;
+    }
+  }
+  state[0] = (double)(it + 1);
+}
+
+__global__ __launch_bounds__(256) void copy_if_kernel(const int* __restrict__ flag, const float* __restrict__ src, float* __restrict__ dst,
+                                                      size_t n) {
+  if (*flag == 0) return;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 inline unsigned nblocks(size_t n) {
   size_t b = cdivz(n, 256);
   if (b > 4096) b = 4096;
@@ -211,4 +252,19 @@ extern "C" int dpi_overlap_normalize(float* acc, int D, int H, int W, int pd, in
   DPI_REQUIRE(acc && pd <= D && ph <= H && pw <= W && sd > 0 && sh > 0 && sw > 0 && gain != 0.f, "overlap_normalize: bad argument");
   overlap_norm_kernel<<<nblocks((size_t)D * H * W), 256, 0, (hipStream_t)stream>>>(acc, D, H, W, pd, ph, pw, sd, sh, sw, gain);
   return dpi_check_launch("overlap_normalize");
+}
+
+extern "C" int dpi_loop_control(const double* metrics, double* state, double* hist, int max_iters, float* step_lr, int* active,
+                                int* improved, int use_plateau, double factor, double threshold, int patience, double min_lr,
+                                double lr_eps, int es_patience, double es_min_delta, void* stream) {
+  DPI_REQUIRE(metrics && state && hist && step_lr && active && improved && max_iters > 0, "loop_control: bad argument");
+  loop_control_kernel<<<1, 64, 0, (hipStream_t)stream>>>(metrics, state, hist, max_iters, step_lr, active, improved, use_plateau, factor,
+                                                        threshold, patience, min_lr, lr_eps, es_patience, es_min_delta);
+  return dpi_check_launch("loop_control");
+}
+
+extern "C" int dpi_copy_if(const int* flag, const float* src, float* dst, size_t n, void* stream) {
+  DPI_REQUIRE(flag && src && dst && n > 0, "copy_if: bad argument");
+  copy_if_kernel<<<nblocks(n), 256, 0, (hipStream_t)stream>>>(flag, src, dst, n);
+  return dpi_check_launch("copy_if");
 }

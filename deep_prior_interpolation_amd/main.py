@@ -127,28 +127,103 @@ class Interpolator:
         self.iiter += 1
         return l
 
-    def optimize(self, net_inputs=None, verbose=True):
-        """Adam loop with optional ReduceLROnPlateau and EarlyStopping (main.py:195-220)."""
+    def optimize(self, net_inputs=None, verbose=True, mode="auto", check_every=64):
+        """Adam loop with optional ReduceLROnPlateau and EarlyStopping (main.py:195-220).
+
+        mode "eager": the reference's control flow, one host read-back of {loss, snr, pcorr} per iteration.
+        mode "graph": iteration 0 runs eagerly, iteration 1 is captured into a hipGraph and replayed; history, best-output
+        tracking, plateau LR and early stopping live on the device (dpi_loop_control / dpi_copy_if), the host only polls
+        the `active` flag every `check_every` replays.  Same arithmetic, same stopping iteration.
+        "auto" picks "graph" unless per-iteration host work was requested (net_inputs, --save_every)."""
         a = self.args
+        if mode == "auto":
+            mode = "eager" if (net_inputs is not None or a.save_every is not None or a.epochs < 3) else "graph"
         self.optimizer = FusedAdam(self.net.parameters(), lr=a.lr)
-        sched = DevicePlateau(self.optimizer, a.lr_factor, a.lr_thresh, a.lr_patience) if a.reduce_lr else None
-        stopper = u.EarlyStopping(patience=a.earlystop_patience, min_delta=a.earlystop_min_delta, percentage=True)
         start = time()
-        for j in range(a.epochs):
-            self.optimizer.zero_grad()
-            loss = self.optimization_loop(None if net_inputs is None else net_inputs[j])
-            self.optimizer.step()
-            if sched is not None:
-                sched.step(loss)
-            if verbose:
-                print(self.history.log_message(self.iiter - 1), "\r", end="")
-            if stopper.step(loss):
-                break
-        torch.cuda.synchronize(self.device)
+        if mode == "graph":
+            self._optimize_graph(verbose, check_every)
+        else:
+            sched = DevicePlateau(self.optimizer, a.lr_factor, a.lr_thresh, a.lr_patience) if a.reduce_lr else None
+            stopper = u.EarlyStopping(patience=a.earlystop_patience, min_delta=a.earlystop_min_delta, percentage=True)
+            for j in range(a.epochs):
+                self.optimizer.zero_grad()
+                loss = self.optimization_loop(None if net_inputs is None else net_inputs[j])
+                self.optimizer.step()
+                if sched is not None:
+                    sched.step(loss)
+                if verbose:
+                    print(self.history.log_message(self.iiter - 1), "\r", end="")
+                if stopper.step(loss):
+                    break
+            torch.cuda.synchronize(self.device)
+            self.out_best = self._to_numpy_out(self._out_best_dev)
         self.elapsed = time() - start
-        self.out_best = self._to_numpy_out(self._out_best_dev)
         if verbose:
             print("\n" + u.sec2time(self.elapsed))
+
+    # ---- hipGraph path -------------------------------------------------------------------------------------
+    def graph_prepare(self):
+        """Allocate the device-resident loop state, run iteration 0 eagerly and capture iteration 1.
+        Returns the captured graph; `graph_finish()` reads history / best output back."""
+        a = self.args
+        L = _lib.load()
+        dev = self.device
+        if self.optimizer is None:
+            self.optimizer = FusedAdam(self.net.parameters(), lr=a.lr)
+        opt = self.optimizer
+        self._g_state = torch.zeros(8, dtype=torch.float64, device=dev)
+        self._g_state[2] = float("inf")
+        self._g_hist = torch.zeros(a.epochs * 4, dtype=torch.float64, device=dev)
+        self._g_improved = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._g_best = None
+        kind = self.loss_kind
+
+        def one_iteration():
+            opt.zero_grad()
+            out_ = self.net(self.perturbed_input())
+            loss, metrics = ops.masked_loss(out_, self.img_, self.mask_, kind)
+            loss.backward()
+            opt.step()                                   # skipped on the device once `active` is 0
+            if self._g_best is None:
+                self._g_best = torch.empty_like(out_)
+            _lib.check(L.dpi_loop_control(_lib.ptr(metrics), _lib.ptr(self._g_state), _lib.ptr(self._g_hist), a.epochs,
+                                          _lib.ptr(opt.step_lr), _lib.ptr(opt.active), _lib.ptr(self._g_improved),
+                                          int(bool(a.reduce_lr)), float(a.lr_factor), float(a.lr_thresh), int(a.lr_patience), 0.0, 1e-8,
+                                          int(a.earlystop_patience), float(a.earlystop_min_delta), _lib.stream()), "dpi_loop_control")
+            _lib.check(L.dpi_copy_if(_lib.ptr(self._g_improved), _lib.ptr(out_), _lib.ptr(self._g_best), out_.numel(),
+                                     _lib.stream()), "dpi_copy_if")
+
+        one_iteration()                                  # iteration 0, eager (also warms every lazy cache)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            one_iteration()                              # recorded, not executed
+        self._graph = graph
+        return graph
+
+    def graph_finish(self):
+        torch.cuda.synchronize(self.device)
+        n = int(self._g_state[0].item())
+        h = self._g_hist[:4 * n].view(n, 4).cpu().numpy()
+        self.history = u.History(self.args.epochs)
+        self.history.loss, self.history.snr, self.history.pcorr, self.history.lr = (h[:, i].tolist() for i in range(4))
+        self.loss_min = float(self._g_state[1].item())
+        self.iiter = n
+        self._out_best_dev = self._g_best
+        self.out_best = self._to_numpy_out(self._g_best)
+
+    def _optimize_graph(self, verbose, check_every):
+        graph = self.graph_prepare()
+        for j in range(1, self.args.epochs):
+            graph.replay()
+            if j % check_every == 0:
+                if int(self.optimizer.active.item()) == 0:     # early stop / NaN decided on the device
+                    break
+                if verbose:
+                    n = int(self._g_state[0].item())
+                    l, s_, p_ = self._g_hist[4 * (n - 1):4 * (n - 1) + 3].tolist()
+                    print("Iter %d, Loss = %+.2e, SNR = %+2.2f dB, PCORR = %+.2f %%" % (n, l, s_, p_ * 100), "\r", end="")
+        self.graph_finish()
 
     # ------------------------------------------------------------------------------------------
     def save_result(self):

@@ -153,6 +153,18 @@ int dpi_adam_multi(const dpi_adam_tensor* tensors, const int64_t* sizes, int nte
                    const float* step_lr, double beta1, double beta2, double eps, const int* active,
                    void* stream);
 
+/* ---------------------------------------------------------------- device-resident loop control --
+ * Replaces the host-side bookkeeping of main.py:165-182,214-217 so that a captured hipGraph of one iteration can be
+ * replayed without host synchronisation: appends {loss, snr, pcorr, lr} to hist[iter], raises *improved when
+ * loss <= loss_min (best-output tracking), runs ReduceLROnPlateau(mode=min, rel threshold) on step_lr[1] and
+ * EarlyStopping(percentage) / NaN stop on *active.  state: double[8], zero-initialised except state[2] = +inf.
+ * dpi_copy_if copies src -> dst only when *flag != 0 (keeps out_best on the device). */
+int dpi_loop_control(const double* metrics, double* state, double* hist, int max_iters, float* step_lr,
+                     int* active, int* improved, int use_plateau, double factor, double threshold,
+                     int patience, double min_lr, double lr_eps, int es_patience, double es_min_delta,
+                     void* stream);
+int dpi_copy_if(const int* flag, const float* src, float* dst, size_t n, void* stream);
+
 /* ---------------------------------------------------------------- input perturbation ------------
  * Replaces main.py:148-150: out = z + std * N(0,1), Philox4x32-10 + Box-Muller, counter = element index,
  * key = (seed, *step_ptr) so that every replay of a captured graph draws fresh noise.
