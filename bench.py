@@ -175,11 +175,19 @@ def main():
         dom_flop = 2.0 * 25 * 27 * 16 * V
         iter_flop = FLOP_PER_VOXEL_ITER * V
         roof = None
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_dominant_conv.json")
+        if tuple(a.patch) == (256, 128, 128) and os.path.exists(tpath):      # PMC passes cannot run inside this process
+            with open(tpath) as fp:
+                tj = json.load(fp)
+            traffic = tj["traffic_bytes_per_launch"]["total"]
+            traffic_src = "profiles/r01_traffic_dominant_conv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated)"
         if dom_ms:
             ach = dom_flop / (dom_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<3,8,2> fwd 25->16 k3 @%dx%dx%d" % tuple(a.patch),
                     "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),
-                    "traffic": None, "launch_ms": round(dom_ms, 4), "launches_timed": len(durs), "launch_timing": timing_src,
+                    "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                    "algorithmic_bytes": 4.0 * (25 + 16) * V, "launch_ms": round(dom_ms, 4), "launches_timed": len(durs), "launch_timing": timing_src,
                     "note": "fp32 FMA-bound stencil (AI 41-44 FLOP/B > ridge 19.7); peak = fp32 vector = fp32 MFMA rate",
                     "whole_iteration": {"achieved_tflops": round(iter_flop / (ms * 1e-3) / 1e12, 3),
                                         "frac_fp32": round(iter_flop / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}}

@@ -65,6 +65,13 @@ struct Geo {
   static constexpr int NB = 3 * NH;                               // LDS values per step
 };
 
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; used for L2 locality only, never for
+// correctness), so give every XCD a CONTIGUOUS range of tiles: halo rows shared by neighbouring tiles then hit the same L2.
+__device__ __forceinline__ int xcd_tile(int bid, int ntiles) {
+  const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, i = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
 template <class G>
 __device__ __forceinline__ void tile_slots(int tid, int id0, int ih0, int iw0, int D, int H, int W, int (&goff)[G::E], int (&loff)[G::E]) {
 #pragma unroll
@@ -118,7 +125,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lk = lane >> 4, lj = lane & 15;
-  int bt = blockIdx.x;
+  const int tile_id = xcd_tile(blockIdx.x, gridDim.x);
+  int bt = tile_id;
   const int tw_i = bt % a.ntw; bt /= a.ntw;
   const int th_i = bt % a.nth; bt /= a.nth;
   const int td_i = bt;
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MArgs a) {
     if (tid < 32) {
       const int c = tid >> 1, which = tid & 1;
       const double rsum = red[0][c][which] + red[1][c][which] + red[2][c][which] + red[3][c][which];
-      if (n0 + c < a.Cout) a.partials[((size_t)blockIdx.x * a.Cout + n0 + c) * 2 + which] = rsum;
+      if (n0 + c < a.Cout) a.partials[((size_t)tile_id * a.Cout + n0 + c) * 2 + which] = rsum;
     }
   }
 }
