@@ -56,6 +56,11 @@ SIGNATURES = {
     "dpi_upsample2x_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dpi_crop_copy": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dpi_crop_copy_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "dpi_maxpool2x2_fwd": (_I, [_P, _I, _I, _I, _P, _P]),
+    "dpi_maxpool2x2_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "dpi_deconv4x4s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "dpi_deconv4x4s2_bwd_data": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "dpi_deconv4x4s2_bwd_weight": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "dpi_loss_ws_doubles": (_Z, [_Z]),
     "dpi_masked_loss": (_I, [_P, _P, _P, _Z, _I, _F, _P, _P, _P, _P]),
     "dpi_adam_multi": (_I, [_P, _P, _I, _P, C.c_double, C.c_double, C.c_double, _P, _P]),

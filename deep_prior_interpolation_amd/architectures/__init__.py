@@ -7,11 +7,12 @@ reference's, built from HIP-backed leaf modules.
 from .base import *            # noqa: F401,F403
 from .mulresunet import *      # noqa: F401,F403
 from .skip import *            # noqa: F401,F403
+from .unet import *            # noqa: F401,F403
+from .unet import UNet
 from .mulresunet import MulResUnet, MulResUnet3D
 from .skip import Skip3D
 
 _OUT_OF_SCOPE = {
-    "unet": "reference get_net names an undefined UNetMod (architectures/__init__.py:13): unreachable upstream",
     "attmultiunet": "AttMulResUnet2D (attention.py) is outside the hot-path scope (SURVEY §2 row 4f)",
     "part": "PartialUNet.forward(x, mask) cannot be called by Interpolator (SURVEY §2 row 4g)",
 }
@@ -24,6 +25,11 @@ def get_net(args, outchannel=1):
     common = dict(num_input_channels=args.inputdepth, num_output_channels=outchannel, upsample_mode=args.upsample,
                   need_bias=True, act_fun=args.activation, last_act_fun=args.last_activation, dropout=args.dropout)
     if args.datadim in ("2d", "2.5d"):
+        if net_name == "unet":
+            # upstream names an undefined `UNetMod` here (architectures/__init__.py:13); the intended class is unet.UNet
+            return UNet(num_input_channels=args.inputdepth, num_output_channels=outchannel, filters=args.filters,
+                        upsample_mode=args.upsample, need_bias=True, act_fun=args.activation,
+                        last_act_fun=args.last_activation, dropout=args.dropout)
         return MulResUnet(num_channels_down=args.filters, num_channels_up=args.filters, num_channels_skip=args.skip, **common)
     if net_name == "skip":
         return Skip3D(num_channels_down=args.filters, num_channels_up=args.filters, num_channels_skip=args.skip, **common)

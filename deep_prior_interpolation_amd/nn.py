@@ -54,6 +54,41 @@ class BatchNorm2d(_BatchNormMixin, nn.BatchNorm2d):
     pass
 
 
+class InstanceNorm2d(nn.Module):
+    """nn.InstanceNorm2d(C) with its defaults (affine=False, no running statistics): for a single patch this is the
+    train-mode BatchNorm kernel with unit scale / zero shift.  No parameters, no state_dict entries (like torch's)."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features = num_features
+        self.register_buffer("_one", torch.ones(num_features), persistent=False)
+        self.register_buffer("_zero", torch.zeros(num_features), persistent=False)
+        self.fused_slope = 1.0
+
+    def forward(self, x):
+        return ops.batch_norm(x, self._one, self._zero, None, None, None, self.fused_slope)
+
+
+class MaxPool2d(nn.Module):
+    def __init__(self, kernel_size=2, stride=2):
+        super().__init__()
+        if kernel_size != 2 or stride != 2:
+            raise NotImplementedError("only MaxPool2d(2, 2)")
+
+    def forward(self, x):
+        return ops.max_pool2x2(x)
+
+
+class ConvTranspose2d(nn.ConvTranspose2d):
+    def __init__(self, in_f, out_f, kernel_size=4, stride=2, padding=1):
+        super().__init__(in_f, out_f, kernel_size, stride=stride, padding=padding)
+        if (kernel_size, stride, padding) != (4, 2, 1):
+            raise NotImplementedError("only ConvTranspose2d(k=4, stride=2, padding=1)")
+
+    def forward(self, x):
+        return ops.conv_transpose4x4s2(x, self.weight, self.bias)
+
+
 class LeakyReLU(nn.Module):
     """LeakyReLU(slope); slope=0 gives ReLU.  (Out of place; the reference's inplace=True is a memory detail.)"""
 

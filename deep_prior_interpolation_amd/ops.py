@@ -413,8 +413,75 @@ class MaskedLossFn(torch.autograd.Function):
         return dout * gloss, None, None, None
 
 
+class MaxPool2x2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(2, 2) on (1,C,H,W) (reference unet.py:42)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x, "maxpool input")
+        if x.ndim != 4 or x.shape[0] != 1:
+            raise _lib.DpiError("maxpool: expected (1,C,H,W)")
+        C_, H, W = x.shape[1:]
+        y = torch.empty((1, C_, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        check(_lib.load().dpi_maxpool2x2_fwd(ptr(x), C_, H, W, ptr(y), stream()), "dpi_maxpool2x2_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        C_, H, W = x.shape[1:]
+        dx = torch.empty_like(x)
+        check(_lib.load().dpi_maxpool2x2_bwd(ptr(_req(dy, "maxpool grad")), ptr(x), C_, H, W, ptr(dx), stream()), "dpi_maxpool2x2_bwd")
+        return dx
+
+
+class Deconv4x4s2Fn(torch.autograd.Function):
+    """nn.ConvTranspose2d(Cin, Cout, 4, stride=2, padding=1) (reference unet.py:59); weight [Cin][Cout][4][4]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _req(x, "deconv input"), _req(w, "deconv weight")
+        if x.ndim != 4 or x.shape[0] != 1 or tuple(w.shape[2:]) != (4, 4) or w.shape[0] != x.shape[1]:
+            raise _lib.DpiError("deconv: expected (1,Cin,H,W) input and [Cin][Cout][4][4] weight")
+        Cin, H, W = x.shape[1:]
+        Cout = w.shape[1]
+        y = torch.empty((1, Cout, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+        check(_lib.load().dpi_deconv4x4s2_fwd(ptr(x), ptr(w), ptr(b), Cin, Cout, H, W, ptr(y), stream()), "dpi_deconv4x4s2_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _req(dy, "deconv grad")
+        Cin, H, W = x.shape[1:]
+        Cout = w.shape[1]
+        L = _lib.load()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(L.dpi_deconv4x4s2_bwd_data(ptr(dy), ptr(w), Cin, Cout, H, W, ptr(dx), stream()), "dpi_deconv4x4s2_bwd_data")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            check(L.dpi_deconv4x4s2_bwd_weight(ptr(x), ptr(dy), Cin, Cout, H, W, ptr(dw), stream()), "dpi_deconv4x4s2_bwd_weight")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+            raw_channel_sum(dy, Cout, dy.numel() // Cout, db)
+        return dx, dw, db
+
+
 def conv(x, w, b, stride=1):
     return ConvFn.apply(x, w, b, stride)
+
+
+def max_pool2x2(x):
+    return MaxPool2x2Fn.apply(x)
+
+
+def conv_transpose4x4s2(x, w, b):
+    return Deconv4x4s2Fn.apply(x, w, b)
 
 
 def batch_norm(x, gamma, beta, running_mean=None, running_var=None, nbt=None, slope=1.0, pre_slope=1.0):

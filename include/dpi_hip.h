@@ -131,6 +131,19 @@ int dpi_crop_copy(const float* x, int C, int D, int H, int W, int od, int oh, in
 int dpi_crop_copy_bwd(const float* dy, int C, int D, int H, int W, int od, int oh, int ow, int Do,
                       int Ho, int Wo, float* dx, void* stream);
 
+/* ---------------------------------------------------------------- plain 2-D UNet extras ----------
+ * Replaces nn.MaxPool2d(2, 2) (unet.py:42) and nn.ConvTranspose2d(Cin, Cout, 4, stride=2, padding=1) (unet.py:59) with
+ * their backward passes.  x: [C][H][W]; pooled / transposed outputs are [C][H/2][W/2] and [Cout][2H][2W];
+ * deconv weight layout is torch's [Cin][Cout][4][4]. */
+int dpi_maxpool2x2_fwd(const float* x, int C, int H, int W, float* y, void* stream);
+int dpi_maxpool2x2_bwd(const float* dy, const float* x, int C, int H, int W, float* dx, void* stream);
+int dpi_deconv4x4s2_fwd(const float* x, const float* w, const float* bias, int Cin, int Cout, int H, int W,
+                        float* y, void* stream);
+int dpi_deconv4x4s2_bwd_data(const float* dy, const float* w, int Cin, int Cout, int H, int W, float* dx,
+                             void* stream);
+int dpi_deconv4x4s2_bwd_weight(const float* x, const float* dy, int Cin, int Cout, int H, int W, float* dw,
+                               void* stream);
+
 /* ---------------------------------------------------------------- loss + metrics ----------------
  * Replaces main.py:161-167: loss = mean(|out*m - img*m|) (kind 0, L1) or mean((.)^2) (kind 1, MSE)
  * over all n elements; dout = dloss/dout * grad_scale; plus the sums for snr/pcorr

@@ -302,9 +302,62 @@ def skip3d_forward(S, x, cfg):
     return out
 
 
+def instance_norm(x, eps=1e-5):
+    """nn.InstanceNorm2d defaults (affine=False, batch statistics): per-channel normalisation of the single patch."""
+    dims = list(range(2, x.ndim))
+    mean = x.mean(dims, keepdim=True)
+    var = ((x - mean) ** 2).mean(dims, keepdim=True)
+    return (x - mean) / torch.sqrt(var + eps)
+
+
+def unet_forward(S, x, cfg):
+    """Plain 2-D UNet (unet.py:84-187) with more_layers=0, concat_x=False, zero padding, InstanceNorm.
+    cfg keys: upsample ('deconv' | 'bilinear' | 'nearest'), act, last_act."""
+    act = cfg.get("act", "LeakyReLU")
+    mode = cfg["upsample"]
+
+    def conv_block(pre, t, norm):
+        t = S.conv(pre + ".0.0", t)
+        if norm:
+            t = instance_norm(t)
+        return activation(act, t)
+
+    def unet_conv(pre, t, norm=True):
+        return conv_block(pre + ".conv2", conv_block(pre + ".conv1", t, norm), norm)
+
+    def down(pre, t):
+        return unet_conv(pre + ".conv", F.max_pool2d(t, 2, 2))
+
+    def up(pre, deep, skip):
+        if mode == "deconv":
+            S.used.update((pre + ".up.weight", pre + ".up.bias"))
+            u = F.conv_transpose2d(deep, S.P[pre + ".up.weight"], S.P[pre + ".up.bias"], stride=2, padding=1)
+        else:
+            u = S.conv(pre + ".up.1.0", upsample2x(deep, mode))
+        return unet_conv(pre + ".conv", concat_crop([u, skip]), norm=False)
+
+    in64 = unet_conv("start", x)
+    d1 = down("down1", in64)
+    d2 = down("down2", d1)
+    d3 = down("down3", d2)
+    d4 = down("down4", d3)
+    u = up("up4", d4, d3)
+    u = up("up3", u, d2)
+    u = up("up2", u, d1)
+    u = up("up1", u, in64)
+    la = cfg.get("last_act")
+    if isinstance(la, str) and la.lower() == "none":
+        la = None
+    if la is not None:
+        return activation(la, S.conv("final.0.0", u))
+    return S.conv("final.0", u)
+
+
 def net_forward(S, x, cfg, taps=None):
     if cfg.get("net", "multiunet") == "skip":
         return skip3d_forward(S, x, cfg)
+    if cfg.get("net") == "unet":
+        return unet_forward(S, x, cfg)
     return mulresunet_forward(S, x, cfg, taps)
 
 

@@ -267,6 +267,33 @@ def gen_nets():
                                      "--upsample", "nearest"], v25 * 1.0, m25, 3, "2.5d"))
 
 
+def gen_unet():
+    """Reference UNet class (architectures/unet.py) driven directly — its own get_net cannot reach it."""
+    import architectures
+    g = torch.Generator().manual_seed(99)
+    out = {}
+    for mode, shape in (("deconv", (1, 6, 32, 32)), ("bilinear", (1, 6, 32, 48)), ("nearest", (1, 6, 34, 38))):
+        m = architectures.UNet(num_input_channels=6, num_output_channels=2, filters=[2, 4, 8, 16, 32], upsample_mode=mode,
+                               act_fun="LeakyReLU")
+        randomize(m, g)
+        d = {"state": sd_np(m), "keys": np.array(json.dumps([[k, list(v.shape)] for k, v in m.state_dict().items()]))}
+        r = fwd_bwd(m, torch.randn(shape, generator=g), g)
+        r.pop("state_after")                      # no buffers in this net: identical to `state`
+        d.update(r)
+        out[mode] = d
+    # leaf ops
+    mp = torch.nn.MaxPool2d(2, 2)
+    out["op_maxpool"] = fwd_bwd(mp, torch.randn((1, 3, 9, 12), generator=g), g)
+    dc = torch.nn.ConvTranspose2d(5, 3, 4, stride=2, padding=1)
+    randomize(dc, g)
+    d = {"state": sd_np(dc)}
+    d.update(fwd_bwd(dc, torch.randn((1, 5, 6, 7), generator=g), g))
+    out["op_deconv"] = d
+    inn = torch.nn.InstanceNorm2d(4)
+    out["op_instnorm"] = fwd_bwd(inn, torch.randn((1, 4, 7, 9), generator=g), g)
+    save("unet", out)
+
+
 def gen_structure():
     """state_dict key/shape tables and parameter counts of the full-size nets."""
     import architectures
@@ -452,7 +479,8 @@ if __name__ == "__main__":
     torch.set_num_threads(THREADS)
     os.makedirs(OUT, exist_ok=True)
     ref_shim.install()
-    todo = {"ops": gen_ops, "blocks": gen_blocks, "nets": gen_nets, "structure": gen_structure, "host": gen_host}
+    todo = {"ops": gen_ops, "blocks": gen_blocks, "nets": gen_nets, "structure": gen_structure, "host": gen_host,
+            "unet": gen_unet}
     for k, fn in todo.items():
         if a.only is None or k in a.only:
             fn()

@@ -186,3 +186,48 @@ def test_graph_mode_device_early_stop_and_plateau(golden):
     np.testing.assert_allclose(out["graph"][0], out["eager"][0], rtol=1e-12)
     np.testing.assert_allclose(out["graph"][1], out["eager"][1], rtol=1e-6)
     assert out["eager"][1][-1] < out["eager"][1][0]                    # the plateau scheduler did reduce the lr
+
+
+@pytest.mark.parametrize("mode", ["deconv", "bilinear", "nearest"])
+def test_unet_golden(golden, mode):
+    """Plain 2-D UNet (MaxPool, InstanceNorm, ConvTranspose2d(4,2,1) / Upsample+conv) on the HIP path vs the reference."""
+    from deep_prior_interpolation_amd.architectures import UNet
+    g = golden("unet")[mode]
+    m = _load_sd(UNet(6, 2, [2, 4, 8, 16, 32], upsample_mode=mode, act_fun="LeakyReLU"), g["state"])
+    x = G(g["x"], True)
+    y = m(x)
+    assert rel(y, g["y"]) < 1e-4
+    y.backward(G(g["dy"]))
+    assert rel(x.grad, g["dx"]) < 2e-4
+    grads = dict(m.named_parameters())
+    for k, p in grads.items():
+        ref = g["grads"][k]
+        if k.endswith("bias") and k.split(".")[0] in ("start", "down1", "down2", "down3", "down4"):
+            wg = np.abs(g["grads"][k[:-4] + "weight"]).max()       # analytically-zero gradient (conv feeds an InstanceNorm)
+            assert float(p.grad.abs().max()) < 1e-3 * wg + 1e-6, k
+        else:
+            assert rel(p.grad, ref) < 5e-4, k
+
+
+def test_unet_leaf_ops_golden(golden):
+    from deep_prior_interpolation_amd import ops
+    g = golden("unet")
+    x = G(g["op_maxpool"]["x"], True)
+    y = ops.max_pool2x2(x)
+    np.testing.assert_array_equal(y.detach().cpu().numpy(), g["op_maxpool"]["y"])
+    y.backward(G(g["op_maxpool"]["dy"]))
+    np.testing.assert_array_equal(x.grad.cpu().numpy(), g["op_maxpool"]["dx"])
+    d = g["op_deconv"]
+    x, w, b = G(d["x"], True), G(d["state"]["weight"], True), G(d["state"]["bias"], True)
+    y = ops.conv_transpose4x4s2(x, w, b)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), d["y"], rtol=1e-5, atol=2e-5)
+    y.backward(G(d["dy"]))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), d["dx"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), d["grads"]["weight"], rtol=1e-5, atol=5e-5)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), d["grads"]["bias"], rtol=1e-5, atol=5e-5)
+    i = g["op_instnorm"]
+    x = G(i["x"], True)
+    y = ops.batch_norm(x, torch.ones(4, device=DEV), torch.zeros(4, device=DEV))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), i["y"], rtol=1e-5, atol=1e-5)
+    y.backward(G(i["dy"]))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), i["dx"], rtol=1e-4, atol=1e-5)

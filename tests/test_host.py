@@ -103,7 +103,7 @@ def test_same_seed_init_is_bit_identical(golden, name):
 
 
 def test_out_of_scope_nets_are_loud():
-    for net in ("unet", "attmultiunet", "part"):
+    for net in ("attmultiunet", "part"):
         with pytest.raises(NotImplementedError):
             get_net(_args(["--imgdir", "x", "--datadim", "2d", "--net", net]), 1)
 
@@ -228,3 +228,14 @@ def test_lines_known_answer(golden):
     img = ln["original"].astype(np.float64)
     std = torch.std(torch.from_numpy((img * ln["mask"]).astype(np.float32))).item()
     assert "%.2e" % std == "3.62e-02"        # proof_of_concept_2D.ipynb:308
+
+
+def test_unet_structure(golden):
+    """--net unet builds the plain UNet with the reference class's state_dict keys, shapes and order."""
+    from deep_prior_interpolation_amd.architectures import UNet
+    for mode in ("deconv", "bilinear", "nearest"):
+        n = UNet(6, 2, [2, 4, 8, 16, 32], upsample_mode=mode, act_fun="LeakyReLU")
+        assert [[k, list(v.shape)] for k, v in n.state_dict().items()] == jstr(golden("unet")[mode]["keys"])
+    a = parse_arguments(["--imgdir", "x", "--datadim", "2d", "--net", "unet", "--upsample", "linear"])
+    assert type(get_net(a, 1)).__name__ == "UNet"
+    assert sum(p.numel() for p in UNet(64, 1).parameters()) == 2472129     # SURVEY §8 a13: class defaults ('deconv'), 64-ch input

@@ -277,3 +277,23 @@ def test_host_misc(golden):
     assert "%.2e" % std == "3.62e-02"
     assert abs(std - float(ln["std"])) < 1e-7
     assert int(ln["kept_traces"]) == 34
+
+
+@pytest.mark.parametrize("mode", ["deconv", "bilinear", "nearest"])
+def test_unet(golden, mode):
+    """Plain 2-D UNet restatement vs the reference's UNet class (forward, input gradient, all parameter gradients)."""
+    g = golden("unet")[mode]
+    S = O.NetState(g["state"])
+    x = T(g["x"], True)
+    y = O.unet_forward(S, x, {"upsample": mode, "act": "LeakyReLU"})
+    assert relnorm(y, g["y"]) < 1e-5
+    y.backward(T(g["dy"]))
+    assert relnorm(x.grad, g["dx"]) < 1e-4
+    for k, v in g["grads"].items():
+        if k.endswith("bias") and k.split(".")[0] in ("start", "down1", "down2", "down3", "down4"):
+            # bias of a conv feeding an InstanceNorm: analytically zero, rounding noise on both sides
+            wg = np.abs(g["grads"][k[:-4] + "weight"]).max()
+            assert np.abs(S.P[k].grad.numpy()).max() < 1e-3 * wg + 1e-6, k
+        else:
+            assert relnorm(S.P[k].grad, v) < 2e-4, k
+    assert S.used == set(S.P.keys())
