@@ -68,6 +68,8 @@ SIGNATURES = {
     "dpi_copy_if": (_I, [_P, _P, _P, _Z, _P]),
     "dpi_noise_add": (_I, [_P, _Z, _F, _U64, _P, _P, _P]),
     "dpi_fill_normal": (_I, [_P, _Z, _F, _F, _U64, _U64, _P]),
+    "dpi_fir_axis0": (_I, [_P, _P, _I, _I, _I, _Z, _P, _P]),
+    "dpi_axpy": (_I, [_F, _P, _Z, _P, _P]),
     "dpi_overlap_add": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
     "dpi_overlap_normalize": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
 }

@@ -359,6 +359,28 @@ __global__ __launch_bounds__(256) void crop_copy_kernel(const float* __restrict_
   }
 }
 
+// y[c][t][s] = sum_k taps[k] * x[c][t + K/2 - k][s]  (zero outside): the grouped conv_transposeNd the reference uses to
+// filter the input noise along the time axis (utils/processing.py:34-67) is a true convolution centred on K/2
+__global__ __launch_bounds__(256) void fir_axis0_kernel(const float* __restrict__ x, const float* __restrict__ taps, int K, int T, size_t S,
+                                                        float* __restrict__ y) {
+  const int c = blockIdx.y, p = K / 2;
+  const size_t n = (size_t)T * S;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i / S);
+    const size_t s_ = i % S;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int tt = t + p - k;
+      if (tt >= 0 && tt < T) acc = fmaf(taps[k], x[(size_t)c * n + (size_t)tt * S + s_], acc);
+    }
+    y[(size_t)c * n + i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float a, const float* __restrict__ x, size_t n, float* __restrict__ y) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = fmaf(a, x[i], y[i]);
+}
+
 inline unsigned ew_blocks(size_t n_vec4_threads) {
   size_t b = cdivz(n_vec4_threads, 256);
   if (b > 4096) b = 4096;
@@ -471,4 +493,16 @@ extern "C" int dpi_crop_copy_bwd(const float* dy, int C, int D, int H, int W, in
   crop_copy_kernel<<<dim3(ew_blocks((size_t)D * H * W), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, od, oh, ow, Do, Ho, Wo, dx,
                                                                                          1);
   return dpi_check_launch("crop_copy_bwd");
+}
+
+extern "C" int dpi_fir_axis0(const float* x, const float* taps, int K, int C, int T, size_t S, float* y, void* stream) {
+  DPI_REQUIRE(x && taps && y && K > 0 && (K & 1) && C > 0 && T > 0 && S > 0, "fir_axis0: bad argument (odd tap count required)");
+  fir_axis0_kernel<<<dim3(ew_blocks((size_t)T * S), C), 256, 0, (hipStream_t)stream>>>(x, taps, K, T, S, y);
+  return dpi_check_launch("fir_axis0");
+}
+
+extern "C" int dpi_axpy(float a, const float* x, size_t n, float* y, void* stream) {
+  DPI_REQUIRE(x && y && n > 0, "axpy: bad argument");
+  axpy_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>(a, x, n, y);
+  return dpi_check_launch("axpy");
 }

@@ -81,17 +81,27 @@ class Interpolator:
         self.num_params = sum(int(np.prod(list(p.size()))) for p in self.net.parameters())
 
     def build_input(self):
-        """z = noise_std * N(0,1) of shape (1, inputdepth, *patch) (main.py:59-64).  The noise filters and the
-        data-forgetting term (main.py:66-97) are not on the HIP path yet."""
+        """z = noise_std * N(0,1) of shape (1, inputdepth, *patch), optionally FIR-filtered along t (wavelet / Butterworth)
+        and prepared for the data-forgetting term (main.py:59-97)."""
         a = self.args
-        if a.filter_noise_with_wavelet or (a.lowpass_fs and a.lowpass_fc) or a.data_forgetting_factor != 0:
-            raise NotImplementedError("input-noise filters / data forgetting are outside the round-1 scope (SURVEY §8f.1)")
         if a.noise_dist != "n":
             z = u.get_noise((1, a.inputdepth) + self.img.shape[:-1], a.noise_dist).to(self.device) * a.noise_std
         else:
             z = torch.empty((1, a.inputdepth) + self.img.shape[:-1], dtype=torch.float32, device=self.device)
             _lib.check(_lib.load().dpi_fill_normal(_lib.ptr(z), z.numel(), 0.0, float(a.noise_std), self.noise_seed,
                                                    0xFFFFFFFF, _lib.stream()), "dpi_fill_normal")
+        if a.filter_noise_with_wavelet:                         # main.py:66-72
+            z = u.ConvolveKernel_1d(kernel=np.load(os.path.join(a.imgdir, "wavelet.npy")), ndim=z.ndim - 2)(z)
+        if a.lowpass_fs and a.lowpass_fc:                       # main.py:74-84: 4th-order Butterworth as an FIR along t
+            z = u.LowPassButterworth(fc=a.lowpass_fc, ndim=z.ndim - 2, fs=a.lowpass_fs, ntaps=a.lowpass_ntaps, order=4,
+                                     nfft=2 ** u.nextpow2(z.shape[2]))(z)
+        if a.data_forgetting_factor != 0:                       # main.py:86-97
+            data_ = self.img_ * self.mask_
+            rep = int(np.ceil(z.shape[1] / data_.shape[1]))
+            data_ = data_.repeat([1, rep] + [1] * (z.ndim - 2))[:, :a.inputdepth].contiguous()
+            data_ = data_ * (torch.std(z) / torch.std(data_))
+            self.add_data_ = data_
+            self.add_data_weight = np.logspace(0, -4, a.data_forgetting_factor)
         self.input_ = z
 
     # ------------------------------------------------------------------------------------------
@@ -112,6 +122,12 @@ class Interpolator:
 
     def optimization_loop(self, net_input=None):
         input_ = self.perturbed_input() if net_input is None else net_input
+        if self.iiter < self.args.data_forgetting_factor:       # main.py:153-155
+            if input_ is self.input_ or net_input is not None:
+                input_ = input_.clone()
+            _lib.check(_lib.load().dpi_axpy(float(self.add_data_weight[self.iiter]), _lib.ptr(self.add_data_), input_.numel(),
+                                            _lib.ptr(input_), _lib.stream()), "dpi_axpy")
+            self.input_list.append(u.torch_to_np(input_, True))
         out_ = self.net(input_)
         total_loss, metrics = ops.masked_loss(out_, self.img_, self.mask_, self.loss_kind)
         total_loss.backward()
@@ -137,7 +153,8 @@ class Interpolator:
         "auto" picks "graph" unless per-iteration host work was requested (net_inputs, --save_every)."""
         a = self.args
         if mode == "auto":
-            mode = "eager" if (net_inputs is not None or a.save_every is not None or a.epochs < 3) else "graph"
+            mode = "eager" if (net_inputs is not None or a.save_every is not None or a.epochs < 3
+                               or a.data_forgetting_factor != 0) else "graph"
         self.optimizer = FusedAdam(self.net.parameters(), lr=a.lr)
         start = time()
         if mode == "graph":

@@ -187,6 +187,12 @@ int dpi_noise_add(const float* z, size_t n, float std, uint64_t seed, const uint
                   float* out, void* stream);
 int dpi_fill_normal(float* out, size_t n, float mean, float std, uint64_t seed, uint64_t stream_id,
                     void* stream);
+/* Replaces utils/processing.py:34-67 (ConvolveKernel_1d: grouped conv_transposeNd with a 1-D kernel along the time
+ * axis, used by --filter_noise_with_wavelet / --lowpass_*): y[c][t][s] = sum_k taps[k] * x[c][t + K/2 - k][s],
+ * x: [C][T][S] with S = product of the remaining spatial axes; K odd; taps on the device. */
+int dpi_fir_axis0(const float* x, const float* taps, int K, int C, int T, size_t S, float* y, void* stream);
+/* y += a * x  (data-forgetting term of main.py:153-154) */
+int dpi_axpy(float a, const float* x, size_t n, float* y, void* stream);
 
 /* ---------------------------------------------------------------- patch reassembly --------------
  * Replaces PatchExtractor.reconstruct (utils/patch_extractor.py:395-428): overlap-add of one patch

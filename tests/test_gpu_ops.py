@@ -314,3 +314,36 @@ def test_conv_adjoint_and_linearity_at_full_size(ops):
         y2 = ops.conv(x2, w.detach(), None, s)
         y12 = ops.conv(x + x2, w.detach(), None, s)
         assert rel(y12, y.detach() + y2) < 5e-6
+
+
+def test_input_noise_fir_filters_golden(golden):
+    """--filter_noise_with_wavelet / --lowpass_* path: FIR along the time axis (reference ConvolveKernel_1d, utils/processing.py:34-79)."""
+    from deep_prior_interpolation_amd import utils as u
+    g = golden("host")["fir"]
+    for tag in ("nd2", "nd3"):
+        c = g[tag]
+        y = u.ConvolveKernel_1d(kernel=c["taps"], ndim=c["x"].ndim - 2)(G(c["x"]))
+        np.testing.assert_allclose(y.cpu().numpy(), c["y"], rtol=1e-5, atol=1e-6)
+    fc, fs, ntaps, order, nfft = g["butter"]["cfg"]
+    np.testing.assert_allclose(u.butterworth_fir_taps(fc, fs, int(ntaps), int(order), int(nfft)), g["butter"]["taps"], rtol=1e-10, atol=1e-12)
+
+
+def test_data_forgetting_and_filters_in_build_input():
+    """build_input with --lowpass_* and --data_forgetting_factor: shapes, normalisation and the per-iteration axpy."""
+    from deep_prior_interpolation_amd.main import Interpolator
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    a = parse_arguments(["--imgdir", "x", "--datadim", "3d", "--filters", "4", "8", "--skip", "4", "--inputdepth", "6", "--epochs", "4",
+                         "--lowpass_fs", "250", "--lowpass_fc", "20", "--data_forgetting_factor", "3", "--gpu", "0"])
+    rng = np.random.RandomState(0)
+    img = rng.randn(16, 8, 8, 1)
+    mask = np.broadcast_to((rng.rand(1, 8, 8, 1) > 0.4).astype(np.float64), img.shape).copy()
+    T = Interpolator(a, "/tmp")
+    T.load_data({"image": img, "mask": mask, "name": "0"})
+    T.build_model()
+    T.build_input()
+    assert T.input_.shape == (1, 6, 16, 8, 8) and T.add_data_.shape == (1, 6, 16, 8, 8)
+    assert abs(float(T.add_data_.std()) - float(T.input_.std())) < 1e-6 * float(T.input_.std()) + 1e-7
+    np.testing.assert_allclose(T.add_data_weight, np.logspace(0, -4, 3))
+    T.optimize(verbose=False)
+    assert len(T.history.loss) == 4 and len(T.input_list) == 3 and T.input_list[0].shape == (6, 16, 8, 8)
+    assert np.isfinite(T.history.loss).all()
