@@ -53,7 +53,11 @@ struct Geo {
   static constexpr int IH = (TY - 1) * S + 3;
   static constexpr int IW = (TW - 1) * S + 3;
   static constexpr int RS = (IW + 3) & ~3;                        // row stride (floats)
-  static constexpr int CS0 = ID * IH * RS;
+  // depth-slice stride: for the stride-1 tiles (RS = 4 mod 32) pad to 12 (mod 32) so that the 9 (kd,kh) row offsets
+  // kd*12 + kh*4 of one backward-weight tap tile fall on disjoint 4-bank slots (kw + voxel spread = 4 banks)
+  static constexpr int DS0 = IH * RS;
+  static constexpr int DS = (S == 1 && (RS % 32) == 4) ? DS0 + ((12 - (DS0 % 32)) + 32) % 32 : DS0;
+  static constexpr int CS0 = ID * DS;
   // lanes of one ds_read_b32 group are 16 voxels (lane stride S) x 2 channels: channel stride = 16 (mod 32 banks) for
   // unit stride, odd (= 1 mod 32) for stride 2 (even banks for one channel, odd banks for the other)
   static constexpr int CSM = S == 1 ? 16 : 1;
@@ -82,7 +86,7 @@ __device__ __forceinline__ void tile_slots(int tid, int id0, int ih0, int iw0, i
     const int gd = id0 + dz, gh = ih0 + hy, gw = iw0 + col;
     const bool ok = idx < G::TILE && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
     goff[e] = ok ? (gd * H + gh) * W + gw : -1;
-    loff[e] = idx < G::TILE ? (dz * G::IH + hy) * G::RS + col : -1;
+    loff[e] = idx < G::TILE ? dz * G::DS + hy * G::RS + col : -1;
   }
 }
 
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MArgs a) {
   tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
 
   const int wz = G::SLICES ? wid : 0, wh = G::SLICES ? 0 : wid * NR;
-  const int lbase = lk * G::CS + (wz * G::SD * G::IH + wh * S) * G::RS + lj * S;
+  const int lbase = lk * G::CS + wz * G::SD * G::DS + wh * S * G::RS + lj * S;
 
   f32x4 acc[NT];
 #pragma unroll
@@ -176,24 +180,26 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MArgs a) {
 #pragma unroll
       for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) b[h * 3 + kw] = lds[lbase + (kd * G::IH + ir) * G::RS + h * 16 * S + kw];
+        for (int kw = 0; kw < 3; ++kw) b[h * 3 + kw] = lds[lbase + kd * G::DS + ir * G::RS + h * 16 * S + kw];
     };
     load_b(bc, 0);
 #pragma unroll
     for (int step = 0; step < G::NSTEP; ++step) {
       if (step + 1 < G::NSTEP) load_b(bn, step + 1);
       const int kd = step / G::NROW, ir = step % G::NROW;
+      // kw outermost: consecutive MFMAs go to DIFFERENT accumulators (a dependent 16x16x4 f32 MFMA needs 40 cycles,
+      // an independent one issues every 32)
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int hr = (ir - kh) / S;                    // output row fed by this input row through tap kh
-        if (ir - kh >= 0 && (ir - kh) % S == 0 && hr < NR) {
+      for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-          for (int h = 0; h < NH; ++h)
+        for (int kh = 0; kh < 3; ++kh) {
+          const int hr = (ir - kh) / S;                  // output row fed by this input row through tap kh
+          if (ir - kh >= 0 && (ir - kh) % S == 0 && hr < NR) {
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
+            for (int h = 0; h < NH; ++h)
               acc[hr * NH + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(kd * 3 + kh) * 3 + kw], bc[h * 3 + kw], acc[hr * NH + h], 0, 0, 0);
+          }
         }
-      }
 #pragma unroll
       for (int i = 0; i < G::NB; ++i) bc[i] = bn[i];
     }
@@ -257,9 +263,10 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
   using G = Geo<KD, NR, NH, S>;
   constexpr int TAPS = KD * 9;
   constexpr int PD = (KD - 1) / 2;
-  constexpr int NTT = (TAPS + 15) / 16;       // tap tiles: 2 (3-D), 1 (2-D)
+  constexpr int NQ = 4 * TAPS;                // (channel, tap) columns of this block: 108 (3-D) / 36 (2-D)
+  constexpr int NTQ = (NQ + 15) / 16;         // MFMA column tiles: 7 (96 % full) / 3 (75 %)
   constexpr int KS = 4 * NH;                  // k-steps (4 voxels each) per output row
-  constexpr int LDSF = 4 * G::CS > 4 * 4 * NTT * 256 ? 4 * G::CS : 4 * 4 * NTT * 256;
+  constexpr int LDSF = 4 * G::CS > 4 * NTQ * 256 ? 4 * G::CS : 4 * NTQ * 256;
   __shared__ __attribute__((aligned(16))) float lds[LDSF];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -270,25 +277,24 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
   const size_t Vo = (size_t)Do * Ho * Wo;
   const int wz = G::SLICES ? wid : 0, wh = G::SLICES ? 0 : wid * NR;
 
-  // per-lane tap offsets inside the halo tile
-  int toff[NTT];
+  // per-lane (channel, tap) offsets inside the halo tile: column q = 16 t + lj -> channel q / TAPS, tap q % TAPS
+  int toff[NTQ];
 #pragma unroll
-  for (int tt = 0; tt < NTT; ++tt) {
-    int tap = tt * 16 + lj;
-    if (tap >= TAPS) tap = TAPS - 1;           // unused columns: any valid address
+  for (int t = 0; t < NTQ; ++t) {
+    int q = t * 16 + lj;
+    if (q >= NQ) q = NQ - 1;                   // unused columns: any valid address
+    const int c = q / TAPS, tap = q % TAPS;
     const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-    toff[tt] = (kd * G::IH + kh) * G::RS + kw;
+    toff[t] = c * G::CS + kd * G::DS + kh * G::RS + kw;
   }
-  const int lbase = (wz * G::SD * G::IH + wh * S) * G::RS + lk * S;
+  const int lbase = wz * G::SD * G::DS + wh * S * G::RS + lk * S;
   const int co_a = n0 + lj;
   const bool co_ok = co_a < a.Cout;
   const float* __restrict__ dyc = a.dy + (size_t)(co_ok ? co_a : 0) * Vo;
 
-  f32x4 acc[4][NTT];
+  f32x4 acc[NTQ];
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int tt = 0; tt < NTT; ++tt) acc[c][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NTQ; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int t_begin = blockIdx.x * a.tiles_per_chunk;
   const int t_end = min(t_begin + a.tiles_per_chunk, a.ntiles);
@@ -311,11 +317,6 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
     stage_store<G>(lds, sr, a.chain, a.Cin, c0, goff, loff);
     __syncthreads();
     const int cod = od0 + wz, coh0 = oh0 + wh, cow0 = ow0;
-    if (tile + 1 < t_end) {                                  // prefetch the next tile behind this tile's MFMAs
-      tile_origin(tile + 1, od0, oh0, ow0);
-      tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
-      stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
-    }
     auto load_g = [&](float (&g)[KS], int hr) {
       const int oh = coh0 + hr;
       const bool row_ok = co_ok && cod < Do && oh < Ho;
@@ -326,40 +327,43 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
         g[s] = (row_ok && ow < Wo) ? dyc[rbase + ow] : 0.f;
       }
     };
-    float g[KS], gn[KS];
-    load_g(g, 0);
+    // vmcnt retires in order: dy rows requested AFTER the next tile's prefetch would make their first use wait for the
+    // whole prefetch.  So the first rows are requested before it, later rows two rows ahead of their use.
+    constexpr int NPRE = NR < 4 ? NR : 4;
+    float g[NR][KS];
+#pragma unroll
+    for (int hr = 0; hr < NPRE; ++hr) load_g(g[hr], hr);
+    if (tile + 1 < t_end) {                                  // prefetch the next tile behind this tile's MFMAs
+      tile_origin(tile + 1, od0, oh0, ow0);
+      tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
+      stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
+    }
 #pragma unroll
     for (int hr = 0; hr < NR; ++hr) {
-      if (hr + 1 < NR) load_g(gn, hr + 1);               // next row's dy behind this row's MFMAs
+      if (hr >= 2 && hr + 2 < NR && hr + 2 >= NPRE) load_g(g[hr + 2], hr + 2);
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int tt = 0; tt < NTT; ++tt) {
-            const float b = lds[c * G::CS + lbase + hr * S * G::RS + 4 * s * S + toff[tt]];
-            acc[c][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[s], b, acc[c][tt], 0, 0, 0);
-          }
+        for (int t = 0; t < NTQ; ++t) {
+          const float b = lds[lbase + hr * S * G::RS + 4 * s * S + toff[t]];
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[hr][s], b, acc[t], 0, 0, 0);
+        }
       }
-#pragma unroll
-      for (int s = 0; s < KS; ++s) g[s] = gn[s];
     }
   }
   // ---- cross-wave reduction through LDS, then one partial per (chunk, co, ci, tap) ------------------------------------
   __syncthreads();
-  float* red = lds;   // [4 waves][4 ci][NTT][4 r][64 lanes]
+  float* red = lds;   // [4 waves][NTQ][4 r][64 lanes]
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int t = 0; t < NTQ; ++t)
 #pragma unroll
-    for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[(((wid * 4 + c) * NTT + tt) * 4 + r) * 64 + lane] = acc[c][tt][r];
+    for (int r = 0; r < 4; ++r) red[((wid * NTQ + t) * 4 + r) * 64 + lane] = acc[t][r];
   __syncthreads();
-  for (int e = tid; e < 4 * NTT * 4 * 64; e += 256) {
-    const int l = e & 63, r = (e >> 6) & 3, tt = (e >> 8) % NTT, c = (e >> 8) / NTT;
-    const float sum = red[e] + red[e + 4 * NTT * 256] + red[e + 2 * 4 * NTT * 256] + red[e + 3 * 4 * NTT * 256];
-    const int co = n0 + 4 * (l >> 4) + r, tap = tt * 16 + (l & 15), ci = c0 + c;
-    if (co < a.Cout && ci < a.Cin && tap < TAPS)
+  for (int e = tid; e < NTQ * 256; e += 256) {
+    const int l = e & 63, r = (e >> 6) & 3, t = e >> 8;
+    const float sum = red[e] + red[e + NTQ * 256] + red[e + 2 * NTQ * 256] + red[e + 3 * NTQ * 256];
+    const int co = n0 + 4 * (l >> 4) + r, q = t * 16 + (l & 15), ci = c0 + q / TAPS, tap = q % TAPS;
+    if (co < a.Cout && q < NQ && ci < a.Cin)
       a.ws[(((size_t)blockIdx.x * a.Cout + co) * a.Cin + ci) * TAPS + tap] = sum;
   }
 }
@@ -694,7 +698,7 @@ static MfmaBwPlan mfma_bw_plan(const dpi_conv_desc* d) {
   const size_t per = (size_t)d->Cout * d->Cin * d->kd * 9;
   const size_t max_chunks_mem = per ? ((size_t)32 << 20) / per : 1;
   const size_t blocks_other = (size_t)cdiv(d->Cin, 4) * cdiv(d->Cout, 16);
-  size_t want = cdivz(1024, blocks_other);
+  size_t want = cdivz(2048, blocks_other);
   if (want > (size_t)p.ntiles) want = p.ntiles;
   if (want > max_chunks_mem) want = max_chunks_mem;
   if (want < 1) want = 1;
