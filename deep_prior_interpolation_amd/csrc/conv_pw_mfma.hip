@@ -29,13 +29,27 @@ struct PwMArgs {
   int accumulate;
 };
 
-// block = 4 waves = 1024 voxels (wave w takes 64-voxel groups w, w+4, w+8, w+12); MT cout tiles per block
-template <int MT>
+// block = 4 waves = 1024 voxels (wave w takes 64-voxel groups w, w+4, w+8, w+12); MT cout tiles per block.
+// WLDS: the block's weight tile [Cin/4 chunks][MT][64 lanes] is gathered ONCE into LDS in MFMA-operand order (lane-linear,
+// conflict-free ds_read_b32), so the streaming loop's only global loads are the activations.
+constexpr int kPwLdsFloats = 12288;     // 48 KiB
+
+template <int MT, bool WLDS>
 __global__ __launch_bounds__(256) void conv_pw_mfma_kernel(PwMArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lk = lane >> 4, lj = lane & 15;
   const int n0 = blockIdx.y * 16 * MT;
   const bool vec = (a.V & 3) == 0;
+  const int nchunk = (a.Cin + 3) >> 2;
+  __shared__ float wl[WLDS ? kPwLdsFloats : 1];
+  if constexpr (WLDS) {
+    for (int e = tid; e < nchunk * MT * 64; e += 256) {
+      const int l = e & 63, m = (e >> 6) % MT, ch = (e >> 6) / MT;
+      const int co = n0 + m * 16 + (l & 15), ci = ch * 4 + (l >> 4);
+      wl[e] = (co < a.Cout && ci < a.Cin) ? a.w[co * a.w_out_stride + ci * a.w_in_stride] : 0.f;
+    }
+    __syncthreads();
+  }
   double ssum[MT][4], qsum[MT][4];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -50,8 +64,9 @@ __global__ __launch_bounds__(256) void conv_pw_mfma_kernel(PwMArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[m][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < a.Cin; c0 += 4) {
-      const int ci = c0 + lk;
+#pragma unroll 4
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int ci = ch * 4 + lk;
       const bool cok = ci < a.Cin;
       float b[4] = {0.f, 0.f, 0.f, 0.f};
       if (cok) {
@@ -71,8 +86,12 @@ __global__ __launch_bounds__(256) void conv_pw_mfma_kernel(PwMArgs a) {
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int co = n0 + m * 16 + lj;
-        const float wv = (cok && co < a.Cout) ? a.w[co * a.w_out_stride + ci * a.w_in_stride] : 0.f;
+        float wv;
+        if constexpr (WLDS) wv = wl[(ch * MT + m) * 64 + lane];
+        else {
+          const int co = n0 + m * 16 + lj;
+          wv = (cok && co < a.Cout) ? a.w[co * a.w_out_stride + ci * a.w_in_stride] : 0.f;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[m][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, b[e], acc[m][e], 0, 0, 0);
       }
@@ -249,9 +268,12 @@ int dpi_conv_pw_mfma_run(const dpi_conv_desc* d, const float* x, const float* ch
   const long w_out = flip ? 1 : (long)d->Cin, w_in = flip ? (long)d->Cin : 1;
   PwMArgs a{x, chain, w, bias, y, partials, cin, cout, (size_t)d->D * d->H * d->W, w_out, w_in, accumulate};
   const unsigned gx = (unsigned)cdivz(a.V, 1024);
-  if (cout <= 16) conv_pw_mfma_kernel<1><<<dim3(gx, 1), 256, 0, st>>>(a);
-  else if (cout <= 32) conv_pw_mfma_kernel<2><<<dim3(gx, 1), 256, 0, st>>>(a);
-  else conv_pw_mfma_kernel<4><<<dim3(gx, cdiv(cout, 64)), 256, 0, st>>>(a);
+  const int mt = cout <= 16 ? 1 : (cout <= 32 ? 2 : 4);
+  const bool wlds = (long)cdiv(cin, 4) * mt * 64 <= kPwLdsFloats;
+  const dim3 grid(gx, cdiv(cout, 16 * mt));
+  if (mt == 1) { if (wlds) conv_pw_mfma_kernel<1, true><<<grid, 256, 0, st>>>(a); else conv_pw_mfma_kernel<1, false><<<grid, 256, 0, st>>>(a); }
+  else if (mt == 2) { if (wlds) conv_pw_mfma_kernel<2, true><<<grid, 256, 0, st>>>(a); else conv_pw_mfma_kernel<2, false><<<grid, 256, 0, st>>>(a); }
+  else { if (wlds) conv_pw_mfma_kernel<4, true><<<grid, 256, 0, st>>>(a); else conv_pw_mfma_kernel<4, false><<<grid, 256, 0, st>>>(a); }
   return dpi_check_launch("conv_pw_mfma");
 }
 
