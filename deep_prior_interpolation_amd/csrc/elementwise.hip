@@ -339,6 +339,108 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
   }
 }
 
+// ---- x2 linear up-sampling, fast 3-D / 2-D paths ------------------------------------------------------------------------
+// forward: one thread per INPUT voxel produces its 2x2x2 output cube from the 3x3x3 (edge-clamped) neighbourhood:
+//   out[2i] = .25 in[i-1] + .75 in[i],  out[2i+1] = .75 in[i] + .25 in[i+1]   per axis (27 loads for 8 outputs)
+template <bool SCALE_D>
+__global__ __launch_bounds__(256) void upsample_lin_fwd_cube_kernel(const float* __restrict__ x, const float* __restrict__ chain, int D, int H,
+                                                                    int W, int Do, int Ho, int Wo, float* __restrict__ y) {
+  const int c = blockIdx.y;
+  const size_t V = (size_t)D * H * W, Vo = (size_t)Do * Ho * Wo;
+  const Chain t = load_chain(chain, c);
+  const float* __restrict__ xc = x + (size_t)c * V;
+  float* __restrict__ yc = y + (size_t)c * Vo;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
+    const int w = i % W, h = (i / W) % H, d = i / ((size_t)W * H);
+    const int wm = max(w - 1, 0), wp = min(w + 1, W - 1), hm = max(h - 1, 0), hp = min(h + 1, H - 1);
+    const int dm = SCALE_D ? max(d - 1, 0) : d, dp = SCALE_D ? min(d + 1, D - 1) : d;
+    const int ds_[3] = {dm, d, dp}, hs_[3] = {hm, h, hp}, ws_[3] = {wm, w, wp};
+    // reduce along w first: for each (dz, hy) the two w-outputs
+    float lo[3][3], hi[3][3];
+#pragma unroll
+    for (int a = 0; a < (SCALE_D ? 3 : 1); ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const float* row = xc + ((size_t)ds_[SCALE_D ? a : 1] * H + hs_[b]) * W;
+        const float v0 = apply_chain(t, row[ws_[0]]), v1 = apply_chain(t, row[ws_[1]]), v2 = apply_chain(t, row[ws_[2]]);
+        lo[a][b] = .25f * v0 + .75f * v1;
+        hi[a][b] = .75f * v1 + .25f * v2;
+      }
+#pragma unroll
+    for (int od_ = 0; od_ < (SCALE_D ? 2 : 1); ++od_) {
+      const int od = SCALE_D ? 2 * d + od_ : d;
+      if (od >= Do) continue;
+#pragma unroll
+      for (int oh_ = 0; oh_ < 2; ++oh_) {
+        const int oh = 2 * h + oh_;
+        if (oh >= Ho) continue;
+        float r0, r1;
+        auto hcomb = [&](int a, float& l, float& u) {
+          l = oh_ == 0 ? .25f * lo[a][0] + .75f * lo[a][1] : .75f * lo[a][1] + .25f * lo[a][2];
+          u = oh_ == 0 ? .25f * hi[a][0] + .75f * hi[a][1] : .75f * hi[a][1] + .25f * hi[a][2];
+        };
+        if (SCALE_D) {
+          float l0, u0, l1, u1, l2, u2;
+          hcomb(0, l0, u0); hcomb(1, l1, u1); hcomb(2, l2, u2);
+          r0 = od_ == 0 ? .25f * l0 + .75f * l1 : .75f * l1 + .25f * l2;
+          r1 = od_ == 0 ? .25f * u0 + .75f * u1 : .75f * u1 + .25f * u2;
+        } else {
+          hcomb(0, r0, r1);
+        }
+        float* op = yc + ((size_t)od * Ho + oh) * Wo + 2 * w;
+        if (2 * w < Wo) op[0] = r0;
+        if (2 * w + 1 < Wo) op[1] = r1;
+      }
+    }
+  }
+}
+
+// backward: one thread per INPUT voxel gathers its 4x4x4 (3-D) / 4x4 (2-D) output neighbourhood with per-axis weights
+//   o = 2i-1: .25   o = 2i: .75 (+.25 at i = 0)   o = 2i+1: .75 (+.25 at i = n-1)   o = 2i+2: .25      (0 outside / cropped)
+__device__ __forceinline__ void lin_bwd_taps(int i, int n, int no, int (&o)[4], float (&wt)[4]) {
+  o[0] = 2 * i - 1; o[1] = 2 * i; o[2] = 2 * i + 1; o[3] = 2 * i + 2;
+  wt[0] = i > 0 ? .25f : 0.f;
+  wt[1] = i == 0 ? 1.f : .75f;
+  wt[2] = i == n - 1 ? 1.f : .75f;
+  wt[3] = i < n - 1 ? .25f : 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (o[k] < 0 || o[k] >= no) { wt[k] = 0.f; o[k] = 0; }
+  }
+}
+
+template <bool SCALE_D>
+__global__ __launch_bounds__(256) void upsample_lin_bwd_gather_kernel(const float* __restrict__ dy, int D, int H, int W, int Do, int Ho,
+                                                                      int Wo, float* __restrict__ dx) {
+  const int c = blockIdx.y;
+  const size_t V = (size_t)D * H * W, Vo = (size_t)Do * Ho * Wo;
+  const float* __restrict__ gc = dy + (size_t)c * Vo;
+  float* __restrict__ oc = dx + (size_t)c * V;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
+    const int w = i % W, h = (i / W) % H, d = i / ((size_t)W * H);
+    int ow[4], oh[4], od[4];
+    float ww[4], wh[4], wd[4];
+    lin_bwd_taps(w, W, Wo, ow, ww);
+    lin_bwd_taps(h, H, Ho, oh, wh);
+    if (SCALE_D) lin_bwd_taps(d, D, Do, od, wd);
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < (SCALE_D ? 4 : 1); ++a) {
+      const int od_ = SCALE_D ? od[a] : d;
+      const float wa = SCALE_D ? wd[a] : 1.f;
+      float accd = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float* row = gc + ((size_t)od_ * Ho + oh[b]) * Wo;
+        const float rsum = ww[0] * row[ow[0]] + ww[1] * row[ow[1]] + ww[2] * row[ow[2]] + ww[3] * row[ow[3]];
+        accd = fmaf(wh[b], rsum, accd);
+      }
+      acc = fmaf(wa, accd, acc);
+    }
+    oc[i] = acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void crop_copy_kernel(const float* __restrict__ x, int D, int H, int W, int od, int oh, int ow,
                                                         int Do, int Ho, int Wo, float* __restrict__ y, int adjoint) {
   // forward: y[c][Do][Ho][Wo] = x[c][od+.., oh+.., ow+..]; adjoint: x-shaped output, zero outside the window
@@ -465,7 +567,12 @@ extern "C" int dpi_upsample2x_fwd(const float* x, const float* chain, int C, int
   const int scale_d = !(D == 1 && Do == 1);
   DPI_REQUIRE(Do >= 1 && Ho >= 1 && Wo >= 1 && Do <= (scale_d ? 2 * D : 1) && Ho <= 2 * H && Wo <= 2 * W,
               "upsample_fwd: output (%d,%d,%d) exceeds 2x input (%d,%d,%d)", Do, Ho, Wo, D, H, W);
-  const size_t Vo = (size_t)Do * Ho * Wo;
+  const size_t Vo = (size_t)Do * Ho * Wo, V = (size_t)D * H * W;
+  if (linear && H > 1 && W > 1 && (!scale_d || D > 1)) {
+    if (scale_d) upsample_lin_fwd_cube_kernel<true><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, y);
+    else upsample_lin_fwd_cube_kernel<false><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, y);
+    return dpi_check_launch("upsample_lin_fwd_cube");
+  }
   upsample_fwd_kernel<<<dim3(ew_blocks(Vo), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, linear, scale_d, y);
   return dpi_check_launch("upsample_fwd");
 }
@@ -475,6 +582,11 @@ extern "C" int dpi_upsample2x_bwd(const float* dy, int C, int D, int H, int W, i
   DPI_REQUIRE(dy && dx && C > 0 && D > 0 && H > 0 && W > 0, "upsample_bwd: bad argument");
   const int scale_d = !(D == 1 && Do == 1);
   const size_t V = (size_t)D * H * W;
+  if (linear) {
+    if (scale_d) upsample_lin_bwd_gather_kernel<true><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, dx);
+    else upsample_lin_bwd_gather_kernel<false><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, dx);
+    return dpi_check_launch("upsample_lin_bwd_gather");
+  }
   upsample_bwd_kernel<<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, linear, scale_d, dx);
   return dpi_check_launch("upsample_bwd");
 }
