@@ -45,10 +45,11 @@ SIGNATURES = {
     "dpi_set_bwd_weight_mfma_min_cout": (None, [_I]),
     "dpi_stat_blocks": (_I, [_I, _Z]),
     "dpi_channel_stats": (_I, [_P, _P, _I, _Z, _P, _P]),
-    "dpi_bn_finalize": (_I, [_P, _I, _I, _Z, _P, _P, _F, _F, _F, _I, _P, _P, _P, _P, _P, _P]),
+    "dpi_bn_finalize": (_I, [_P, _I, _I, _Z, _P, _P, _F, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P]),
     "dpi_chain_apply": (_I, [_P, _P, _I, _Z, _P, _P]),
-    "dpi_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _Z, _P, _P]),
-    "dpi_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _F, _F, _P, _I, _I, _Z, _P, _P, _P, _P]),
+    "dpi_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _I, _Z, _P, _P]),
+    "dpi_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _P, _I, _I, _Z, _P, _P, _P, _P]),
+    "dpi_chain_add_stats": (_I, [_P, _P, _P, _P, _I, _Z, _F, _P, _P, _P]),
     "dpi_lrelu_bwd": (_I, [_P, _P, _F, _Z, _P, _P]),
     "dpi_add": (_I, [_P, _P, _Z, _P, _P]),
     "dpi_channel_sum": (_I, [_P, _I, _Z, _P, _P, _P]),

@@ -15,6 +15,9 @@ from .base import Concat, Seq, conv_bn_act, conv_nd, get_activation
 __all__ = ["MulResUnet", "MulResUnet3D", "MultiResBlock", "ResPath", "multires_widths"]
 
 
+FUSE_BLOCKS = True     # run Block3d / ResPath3d as single fused autograd nodes (ops.Block3dFn / ops.ResPath3dFn)
+
+
 def multires_widths(U, alpha=1.67):
     """Channel split of a MultiRes block (mulresunet.py:14-23, 70-78)."""
     W = alpha * U
@@ -44,7 +47,14 @@ class MultiResBlock(nn.Module):
             self.dr = hnn.Dropout(drop)
             self.act = get_activation(act_fun)
 
+    def _fusable(self):
+        return (self.nd == 3 and isinstance(self.act, hnn.LeakyReLU) and self.dr.p == 0.0
+                and all(isinstance(m._parts()[2], hnn.LeakyReLU) and m._parts()[2].negative_slope == self.act.negative_slope
+                        for m in (self.conv3x3, self.conv5x5, self.conv7x7, self.shortcut)))
+
     def forward(self, x):
+        if FUSE_BLOCKS and self._fusable():
+            return ops.block3d(x, self, self.act.negative_slope)
         o1 = self.conv3x3(x)
         o2 = self.conv5x5(o1)
         o3 = self.conv7x7(o2)
@@ -88,6 +98,10 @@ class ResPath(nn.Module):
             self.net = nn.Sequential(c3, c1, bn, self.dr)
 
     def forward(self, x):
+        if (FUSE_BLOCKS and self.nd == 3 and isinstance(self.act, hnn.LeakyReLU) and self.dr.p == 0.0
+                and all(isinstance(m._parts()[2], hnn.LeakyReLU) and m._parts()[2].negative_slope == self.act.negative_slope
+                        for m in (self.conv3x3, self.conv1x1))):
+            return ops.respath3d(x, self, self.act.negative_slope)
         if self.nd == 3:
             t, b = ops.add(self.conv1x1(x), self.conv3x3(x)), self.bn
         else:

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restrict__ partials, int nblk, int C, double count,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float eps, float momentum, float slope, int act_first,
-                                                         float* running_mean, float* running_var, int64_t* nbt,
+                                                         const float* __restrict__ in_chain, float* running_mean, float* running_var, int64_t* nbt,
                                                          float* __restrict__ mean_invstd, float* __restrict__ chain_out) {
   const int c = blockIdx.x, lane = threadIdx.x;
   double s = 0.0, q = 0.0;
@@ -84,7 +84,10 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restric
       const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
       const float a = g * invstd;
       float* o = chain_out + (size_t)c * DPI_CHAIN_STRIDE;
-      if (act_first) { o[0] = 1.f; o[1] = 0.f; o[2] = slope; o[3] = a; o[4] = bt - meanf * a; }   // BN(act(x))
+      if (in_chain) {   // BN of T_in(x) (no activation after): compose the affine part into T_in's output stage
+        const float* ic = in_chain + (size_t)c * DPI_CHAIN_STRIDE;
+        o[0] = ic[0]; o[1] = ic[1]; o[2] = ic[2]; o[3] = a * ic[3]; o[4] = fmaf(a, ic[4], bt - meanf * a);
+      } else if (act_first) { o[0] = 1.f; o[1] = 0.f; o[2] = slope; o[3] = a; o[4] = bt - meanf * a; }   // BN(act(x))
       else { o[0] = a; o[1] = bt - meanf * a; o[2] = slope; o[3] = 1.f; o[4] = 0.f; }           // act(BN(x))
     }
   }
@@ -115,10 +118,15 @@ __global__ __launch_bounds__(256) void chain_apply_kernel(const float* __restric
 // so neither the activation output nor an intermediate gradient tensor is ever materialised.
 struct BnBwd {
   float mean, invstd, a, pb, pre, post;
+  bool chained;
+  Chain in;   // value-only input transform: the BN input is u = T_in(x) and dx is the gradient w.r.t. u
 };
 __device__ __forceinline__ BnBwd bn_bwd_consts(const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
-                                               const float* __restrict__ beta, float pre, float post, int C, int c) {
+                                               const float* __restrict__ beta, const float* __restrict__ in_chain, float pre,
+                                               float post, int C, int c) {
   BnBwd k;
+  k.chained = in_chain != nullptr;
+  k.in = load_chain(in_chain, c);
   k.mean = mean_invstd[c]; k.invstd = mean_invstd[C + c];
   k.a = (gamma ? gamma[c] : 1.f) * k.invstd;
   k.pb = (beta ? beta[c] : 0.f) - k.mean * k.a;   // same expression as bn_finalize's chain shift: identical activation mask
@@ -127,6 +135,7 @@ __device__ __forceinline__ BnBwd bn_bwd_consts(const float* __restrict__ mean_in
 }
 // returns xhat and the gradient w.r.t. the BN output proper
 __device__ __forceinline__ void bn_bwd_elem(const BnBwd& k, float x, float dy, float& xhat, float& g) {
+  if (k.chained) x = apply_chain(k.in, x);
   const float u = x > 0.f ? x : x * k.pre;
   xhat = (u - k.mean) * k.invstd;
   const float yv = fmaf(k.a, u, k.pb);
@@ -135,12 +144,13 @@ __device__ __forceinline__ void bn_bwd_elem(const BnBwd& k, float x, float dy, f
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float pre, float post, int C, size_t V,
-                                                            int nblk, double* __restrict__ partials) {
+                                                            const float* __restrict__ beta, const float* __restrict__ in_chain,
+                                                            float pre, float post, int C, size_t V, int nblk,
+                                                            double* __restrict__ partials) {
   const int c = blockIdx.y, b = blockIdx.x;
   const size_t span = stat_span(V, nblk);
   const size_t beg = (size_t)b * span, end = beg + span < V ? beg + span : V;
-  const BnBwd k = bn_bwd_consts(mean_invstd, gamma, beta, pre, post, C, c);
+  const BnBwd k = bn_bwd_consts(mean_invstd, gamma, beta, in_chain, pre, post, C, c);
   const float* __restrict__ xc = x + (size_t)c * V;
   const float* __restrict__ gc = dy + (size_t)c * V;
   double s = 0.0, q = 0.0;
@@ -177,8 +187,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float pre, float post,
-                                                           const double* __restrict__ partials, int nblk, int C, size_t V,
+                                                           const float* __restrict__ beta, const float* __restrict__ in_chain,
+                                                           float pre, float post, const double* __restrict__ partials, int nblk, int C, size_t V,
                                                            float* __restrict__ dx, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta) {
   const int c = blockIdx.y;
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     if (threadIdx.x == 0) { tot[0] = s; tot[1] = q; }
   }
   __syncthreads();
-  const BnBwd k = bn_bwd_consts(mean_invstd, gamma, beta, pre, post, C, c);
+  const BnBwd k = bn_bwd_consts(mean_invstd, gamma, beta, in_chain, pre, post, C, c);
   const float k1 = (float)(tot[0] / (double)V), k2 = (float)(tot[1] / (double)V);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (dgamma) dgamma[c] = (float)tot[1];
@@ -218,6 +228,56 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     } else {
       for (int j = 0; j < 4 && i + j < V; ++j) oc[i + j] = one(xc[i + j], gc[i + j]);
     }
+  }
+}
+
+// ---- t = T_a(a) + T_b(b), and {sum, sum^2} of act(t): the residual join of Block3d / ResPath3d in one pass -----------
+__global__ __launch_bounds__(256) void chain_add_stats_kernel(const float* __restrict__ a, const float* __restrict__ chain_a,
+                                                              const float* __restrict__ b, const float* __restrict__ chain_b, int C,
+                                                              size_t V, int nblk, float slope, float* __restrict__ t,
+                                                              double* __restrict__ partials) {
+  const int c = blockIdx.y, blk = blockIdx.x;
+  const size_t span = stat_span(V, nblk);
+  const size_t beg = (size_t)blk * span, end = beg + span < V ? beg + span : V;
+  const Chain ta = load_chain(chain_a, c), tb = load_chain(chain_b, c);
+  const float* __restrict__ ac = a + (size_t)c * V;
+  const float* __restrict__ bc = b + (size_t)c * V;
+  float* __restrict__ tc = t + (size_t)c * V;
+  double s = 0.0, q = 0.0;
+  const bool vec = (V & 3) == 0;
+  for (size_t i = beg + (size_t)threadIdx.x * 4; i < end; i += 1024) {
+    float av[4], bv[4], tv[4];
+    if (vec) {
+      const float4 f = *reinterpret_cast<const float4*>(ac + i);
+      const float4 g = *reinterpret_cast<const float4*>(bc + i);
+      av[0] = f.x; av[1] = f.y; av[2] = f.z; av[3] = f.w;
+      bv[0] = g.x; bv[1] = g.y; bv[2] = g.z; bv[3] = g.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { av[j] = i + j < end ? ac[i + j] : 0.f; bv[j] = i + j < end ? bc[i + j] : 0.f; }
+    }
+    float ls = 0.f;
+    double lq = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tv[j] = apply_chain(ta, av[j]) + apply_chain(tb, bv[j]);
+      if (i + j < end) {
+        const float y = tv[j] > 0.f ? tv[j] : tv[j] * slope;
+        ls += y;
+        lq += (double)y * y;
+      }
+    }
+    if (vec) *reinterpret_cast<float4*>(tc + i) = make_float4(tv[0], tv[1], tv[2], tv[3]);
+    else
+      for (int j = 0; j < 4 && i + j < end; ++j) tc[i + j] = tv[j];
+    s += ls; q += lq;
+  }
+  __shared__ double sh[8];
+  const double S = block_sum(s, sh);
+  const double Q = block_sum(q, sh + 4);
+  if (threadIdx.x == 0) {
+    partials[((size_t)blk * C + c) * 2 + 0] = S;
+    partials[((size_t)blk * C + c) * 2 + 1] = Q;
   }
 }
 
@@ -507,11 +567,13 @@ extern "C" int dpi_channel_stats(const float* x, const float* chain, int C, size
 }
 
 extern "C" int dpi_bn_finalize(const double* partials, int nblk, int C, size_t count, const float* gamma, const float* beta,
-                               float eps, float momentum, float slope, int act_first, float* running_mean, float* running_var,
-                               int64_t* num_batches_tracked, float* mean_invstd, float* chain_out, void* stream) {
+                               float eps, float momentum, float slope, int act_first, const float* in_chain, float* running_mean,
+                               float* running_var, int64_t* num_batches_tracked, float* mean_invstd, float* chain_out,
+                               void* stream) {
   DPI_REQUIRE(partials && nblk > 0 && C > 0 && count > 0, "bn_finalize: bad argument");
+  DPI_REQUIRE(!in_chain || (slope == 1.f && !act_first), "bn_finalize: a composed input chain excludes a fused activation");
   bn_finalize_kernel<<<C, 64, 0, (hipStream_t)stream>>>(partials, nblk, C, (double)count, gamma, beta, eps, momentum, slope, act_first,
-                                                        running_mean, running_var, num_batches_tracked, mean_invstd, chain_out);
+                                                        in_chain, running_mean, running_var, num_batches_tracked, mean_invstd, chain_out);
   return dpi_check_launch("bn_finalize");
 }
 
@@ -522,22 +584,33 @@ extern "C" int dpi_chain_apply(const float* x, const float* chain, int C, size_t
 }
 
 extern "C" int dpi_bn_bwd_reduce(const float* dy, const float* x, const float* mean_invstd, const float* gamma, const float* beta,
-                                 float pre_slope, float post_slope, int C, size_t V, double* partials, void* stream) {
+                                 const float* in_chain, float pre_slope, float post_slope, int C, size_t V, double* partials,
+                                 void* stream) {
   DPI_REQUIRE(dy && x && mean_invstd && partials && C > 0 && V > 0, "bn_bwd_reduce: bad argument");
+  DPI_REQUIRE(!in_chain || pre_slope == 1.f, "bn_bwd_reduce: in_chain excludes pre_slope");
   const int nblk = dpi_stat_blocks(C, V);
-  bn_bwd_reduce_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, beta, pre_slope, post_slope, C, V,
+  bn_bwd_reduce_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, beta, in_chain, pre_slope, post_slope, C, V,
                                                                        nblk, partials);
   return dpi_check_launch("bn_bwd_reduce");
 }
 
 extern "C" int dpi_bn_bwd_apply(const float* dy, const float* x, const float* mean_invstd, const float* gamma, const float* beta,
-                                float pre_slope, float post_slope, const double* partials, int nblk, int C, size_t V, float* dx,
-                                float* dgamma, float* dbeta, void* stream) {
+                                const float* in_chain, float pre_slope, float post_slope, const double* partials, int nblk, int C,
+                                size_t V, float* dx, float* dgamma, float* dbeta, void* stream) {
   DPI_REQUIRE(dy && x && mean_invstd && partials && dx && C > 0 && V > 0 && nblk > 0, "bn_bwd_apply: bad argument");
-  bn_bwd_apply_kernel<<<dim3(ew_blocks(cdivz(V, 4)), C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, beta, pre_slope,
+  DPI_REQUIRE(!in_chain || pre_slope == 1.f, "bn_bwd_apply: in_chain excludes pre_slope");
+  bn_bwd_apply_kernel<<<dim3(ew_blocks(cdivz(V, 4)), C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, beta, in_chain, pre_slope,
                                                                                       post_slope, partials, nblk, C, V, dx, dgamma,
                                                                                       dbeta);
   return dpi_check_launch("bn_bwd_apply");
+}
+
+extern "C" int dpi_chain_add_stats(const float* a, const float* chain_a, const float* b, const float* chain_b, int C, size_t V,
+                                   float slope, float* t, double* partials, void* stream) {
+  DPI_REQUIRE(a && b && t && partials && C > 0 && V > 0, "chain_add_stats: bad argument");
+  const int nblk = dpi_stat_blocks(C, V);
+  chain_add_stats_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(a, chain_a, b, chain_b, C, V, nblk, slope, t, partials);
+  return dpi_check_launch("chain_add_stats");
 }
 
 extern "C" int dpi_lrelu_bwd(const float* dy, const float* x, float slope, size_t n, float* dx, void* stream) {

@@ -118,21 +118,23 @@ def raw_channel_sum(x, C_, V, out):
 
 
 def raw_bn_stats_finalize(x, chain_in, C_, V, gamma, beta, slope, running_mean, running_var, nbt, mean_invstd, chain_out,
-                          eps=BN_EPS, momentum=BN_MOMENTUM, act_first=0):
-    """channel stats of T(x) followed by finalize."""
+                          eps=BN_EPS, momentum=BN_MOMENTUM, act_first=0, compose=False):
+    """channel stats of T(x) followed by finalize (compose=True: chain_out = BN o T_in instead of BN alone)."""
     L = _lib.load()
     nblk = L.dpi_stat_blocks(C_, V)
     part = torch.empty(nblk * C_ * 2, dtype=torch.float64, device=x.device)
     check(L.dpi_channel_stats(ptr(x), ptr(chain_in), C_, V, ptr(part), stream()), "dpi_channel_stats")
-    check(L.dpi_bn_finalize(ptr(part), nblk, C_, V, ptr(gamma), ptr(beta), eps, momentum, slope, act_first, ptr(running_mean),
-                            ptr(running_var), ptr(nbt), ptr(mean_invstd), ptr(chain_out), stream()), "dpi_bn_finalize")
+    check(L.dpi_bn_finalize(ptr(part), nblk, C_, V, ptr(gamma), ptr(beta), eps, momentum, slope, act_first,
+                            ptr(chain_in) if compose else None, ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean_invstd),
+                            ptr(chain_out), stream()), "dpi_bn_finalize")
 
 
 def raw_bn_finalize(part, nblk, C_, count, gamma, beta, slope, running_mean, running_var, nbt, mean_invstd, chain_out,
-                    eps=BN_EPS, momentum=BN_MOMENTUM):
+                    eps=BN_EPS, momentum=BN_MOMENTUM, act_first=0):
     L = _lib.load()
-    check(L.dpi_bn_finalize(ptr(part), nblk, C_, count, ptr(gamma), ptr(beta), eps, momentum, slope, 0, ptr(running_mean),
-                            ptr(running_var), ptr(nbt), ptr(mean_invstd), ptr(chain_out), stream()), "dpi_bn_finalize")
+    check(L.dpi_bn_finalize(ptr(part), nblk, C_, count, ptr(gamma), ptr(beta), eps, momentum, slope, act_first, None,
+                            ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean_invstd), ptr(chain_out), stream()),
+          "dpi_bn_finalize")
 
 
 def raw_chain_apply(x, chain, C_, V, y):
@@ -190,20 +192,22 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
-def _bn_backward(dy, x, mi, gamma, beta, pre_slope, post_slope):
-    """two-phase BatchNorm backward with the surrounding LeakyReLU folded in; returns (dx, dgamma, dbeta)."""
+def _bn_backward(dy, x, mi, gamma, beta, pre_slope, post_slope, in_chain=None, dx=None):
+    """two-phase BatchNorm backward with the surrounding LeakyReLU folded in; returns (dx, dgamma, dbeta).
+    in_chain: the normalised tensor was T_in(x) and dx is the gradient w.r.t. T_in(x); dx: optional output buffer."""
     L = _lib.load()
     C_ = x.shape[1]
     V = x.numel() // C_
     nblk = L.dpi_stat_blocks(C_, V)
     part = torch.empty(nblk * C_ * 2, dtype=torch.float64, device=x.device)
-    check(L.dpi_bn_bwd_reduce(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), pre_slope, post_slope, C_, V, ptr(part), stream()),
-          "dpi_bn_bwd_reduce")
-    dx = torch.empty_like(x)
+    check(L.dpi_bn_bwd_reduce(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), ptr(in_chain), pre_slope, post_slope, C_, V,
+                              ptr(part), stream()), "dpi_bn_bwd_reduce")
+    if dx is None:
+        dx = torch.empty_like(x)
     dgamma = torch.empty_like(gamma)
     dbeta = torch.empty_like(gamma)
-    check(L.dpi_bn_bwd_apply(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), pre_slope, post_slope, ptr(part), nblk, C_, V,
-                             ptr(dx), ptr(dgamma), ptr(dbeta), stream()), "dpi_bn_bwd_apply")
+    check(L.dpi_bn_bwd_apply(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), ptr(in_chain), pre_slope, post_slope, ptr(part), nblk,
+                             C_, V, ptr(dx), ptr(dgamma), ptr(dbeta), stream()), "dpi_bn_bwd_apply")
     return dx, dgamma, dbeta
 
 
@@ -283,6 +287,183 @@ class ConvBnActFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.zeros(d.Cout, dtype=torch.float32, device=x.device)
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None
+
+
+def _cba_raw(d, x, in_chain, w, b, bn, slope, r_out, mi_out, chain_out):
+    """conv(T_in(x)) -> r_out with {sum, sum^2} epilogue -> finalize of `bn` (+ LeakyReLU slope) into (mi_out, chain_out)."""
+    L = _lib.load()
+    nblk = L.dpi_conv_fwd_stat_blocks(C.byref(d))
+    part = torch.empty(nblk * d.Cout * 2, dtype=torch.float64, device=x.device)
+    raw_conv_fwd(d, x, in_chain, w, b, r_out, part)
+    Do, Ho, Wo = desc_out_dims(d)
+    raw_bn_finalize(part, nblk, d.Cout, Do * Ho * Wo, bn.weight, bn.bias, slope, bn.running_mean, bn.running_var,
+                    bn.num_batches_tracked, mi_out, chain_out)
+
+
+def _zeros_like_or_none(b):
+    return None if b is None else torch.zeros_like(b)
+
+
+class Block3dFn(torch.autograd.Function):
+    """Block3d (reference mulresunet.py:67-96) as ONE autograd node:
+         y = bn2(act(CBA1(x) + bn1(cat[o1, o2, o3]))),  o1 = CBA3(x), o2 = CBA3(o1), o3 = CBA3(o2).
+    The three 3x3x3 convs write their RAW outputs into channel slices of one tensor R (zero-copy concat); BN + LeakyReLU
+    of each is a chain applied by whoever loads R (the next conv, the bn1 statistics, the residual join), bn1 is composed
+    into that chain, and the join t = T_s(S) + T_bn1(R) emits the bn2 statistics in the same pass.  Backward accumulates
+    the fan-in gradients inside conv backward-data instead of separate add passes.
+    Elementwise traffic per block: 6 tensor passes forward instead of 15 (in units of out_dim x V floats)."""
+
+    @staticmethod
+    def forward(ctx, x, blk, slope, *p):
+        x = _req(x, "block input")
+        (w1, b1, g1, e1, w2, b2, g2, e2, w3, b3, g3, e3, ws, bs, gs, es, gA, eA, gB, eB) = p
+        L = _lib.load()
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        c1, c2, c3 = w1.shape[0], w2.shape[0], w3.shape[0]
+        Ct = c1 + c2 + c3
+        bn1_, bn2_, bn3_, bns_ = (m._parts()[1] for m in (blk.conv3x3, blk.conv5x5, blk.conv7x7, blk.shortcut))
+        d1 = make_desc(x, w1, 1)
+        Do, Ho, Wo = desc_out_dims(d1)
+        V = Do * Ho * Wo
+        R = torch.empty(_like_spatial(x, Ct, Do, Ho, Wo), **f32)
+        CH = torch.empty(Ct * 5, **f32)
+        r1, r2, r3 = R[:, :c1], R[:, c1:c1 + c2], R[:, c1 + c2:]
+        ch1, ch2, ch3 = CH[:c1 * 5], CH[c1 * 5:(c1 + c2) * 5], CH[(c1 + c2) * 5:]
+        mi1, mi2, mi3 = (torch.empty(2 * c, **f32) for c in (c1, c2, c3))
+        miA, miS, miB = (torch.empty(2 * Ct, **f32) for _ in range(3))
+        _cba_raw(d1, x, None, w1, b1, bn1_, slope, r1, mi1, ch1)
+        d2 = make_desc(r1, w2, 1)
+        _cba_raw(d2, r1, ch1, w2, b2, bn2_, slope, r2, mi2, ch2)
+        d3 = make_desc(r2, w3, 1)
+        _cba_raw(d3, r2, ch2, w3, b3, bn3_, slope, r3, mi3, ch3)
+        # bn1 over the virtual concat T_CH(R); chA = bn1 o T_CH
+        chA = torch.empty(Ct * 5, **f32)
+        A = blk.bn1
+        raw_bn_stats_finalize(R, CH, Ct, V, gA, eA, 1.0, A.running_mean, A.running_var, A.num_batches_tracked, miA, chA,
+                              compose=True)
+        dsc = make_desc(x, ws, 1)
+        S = torch.empty_like(R)
+        chS = torch.empty(Ct * 5, **f32)
+        _cba_raw(dsc, x, None, ws, bs, bns_, slope, S, miS, chS)
+        # residual join + statistics of act(t) for bn2
+        t = torch.empty_like(R)
+        nblk = L.dpi_stat_blocks(Ct, V)
+        part = torch.empty(nblk * Ct * 2, dtype=torch.float64, device=dev)
+        check(L.dpi_chain_add_stats(ptr(S), ptr(chS), ptr(R), ptr(chA), Ct, V, slope, ptr(t), ptr(part), stream()),
+              "dpi_chain_add_stats")
+        chB = torch.empty(Ct * 5, **f32)
+        B = blk.bn2
+        raw_bn_finalize(part, nblk, Ct, V, gB, eB, slope, B.running_mean, B.running_var, B.num_batches_tracked, miB, chB,
+                        act_first=1)
+        y = torch.empty_like(R)
+        raw_chain_apply(t, chB, Ct, V, y)
+        ctx.save_for_backward(x, R, S, t, CH, mi1, mi2, mi3, miA, miS, miB, *[q for q in p if q is not None])
+        ctx.none_mask = [q is None for q in p]
+        ctx.descs = (d1, d2, d3, dsc)
+        ctx.slope = float(slope)
+        ctx.split = (c1, c2, c3)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _req(dy, "block grad")
+        x, R, S, t, CH, mi1, mi2, mi3, miA, miS, miB = ctx.saved_tensors[:11]
+        it = iter(ctx.saved_tensors[11:])
+        p = [None if isnone else next(it) for isnone in ctx.none_mask]
+        (w1, b1, g1, e1, w2, b2, g2, e2, w3, b3, g3, e3, ws, bs, gs, es, gA, eA, gB, eB) = p
+        d1, d2, d3, dsc = ctx.descs
+        slope = ctx.slope
+        c1, c2, c3 = ctx.split
+        s1, s2, s3 = slice(0, c1), slice(c1, c1 + c2), slice(c1 + c2, c1 + c2 + c3)
+        ch1, ch2 = CH[:c1 * 5], CH[c1 * 5:(c1 + c2) * 5]
+        dt, dgB, deB = _bn_backward(dy, t, miB, gB, eB, slope, 1.0)
+        dS, dgs, des = _bn_backward(dt, S, miS, gs, es, 1.0, slope)
+        dcat, dgA, deA = _bn_backward(dt, R, miA, gA, eA, 1.0, 1.0, in_chain=CH)
+        del dt
+        dR = torch.empty_like(R)
+        # o3 -> o2 -> o1: each conv's backward-data ACCUMULATES into the concat gradient of its input slice
+        _, dg3, de3 = _bn_backward(dcat[:, s3], R[:, s3], mi3, g3, e3, 1.0, slope, dx=dR[:, s3])
+        dw3 = torch.empty_like(w3)
+        raw_conv_bwd_weight(d3, R[:, s2], ch2, dR[:, s3], dw3)
+        raw_conv_bwd_data(d3, dR[:, s3], w3, dcat[:, s2], accumulate=True)
+        _, dg2, de2 = _bn_backward(dcat[:, s2], R[:, s2], mi2, g2, e2, 1.0, slope, dx=dR[:, s2])
+        dw2 = torch.empty_like(w2)
+        raw_conv_bwd_weight(d2, R[:, s1], ch1, dR[:, s2], dw2)
+        raw_conv_bwd_data(d2, dR[:, s2], w2, dcat[:, s1], accumulate=True)
+        _, dg1, de1 = _bn_backward(dcat[:, s1], R[:, s1], mi1, g1, e1, 1.0, slope, dx=dR[:, s1])
+        dw1 = torch.empty_like(w1)
+        raw_conv_bwd_weight(d1, x, None, dR[:, s1], dw1)
+        dws = torch.empty_like(ws)
+        raw_conv_bwd_weight(dsc, x, None, dS, dws)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            raw_conv_bwd_data(dsc, dS, ws, dx)
+            raw_conv_bwd_data(d1, dR[:, s1], w1, dx, accumulate=True)
+        z = _zeros_like_or_none      # conv biases feed a BatchNorm: analytically zero gradient (SURVEY App. D)
+        return (dx, None, None, dw1, z(b1), dg1, de1, dw2, z(b2), dg2, de2, dw3, z(b3), dg3, de3, dws, z(bs), dgs, des,
+                dgA, deA, dgB, deB)
+
+
+class ResPath3dFn(torch.autograd.Function):
+    """ResPath3d (reference mulresunet.py:99-113) as one autograd node: y = bn(act(CBA1(x) + CBA3(x)))."""
+
+    @staticmethod
+    def forward(ctx, x, rp, slope, *p):
+        x = _req(x, "respath input")
+        (w3, b3, g3, e3, w1, b1, g1, e1, gB, eB) = p
+        L = _lib.load()
+        f32 = dict(dtype=torch.float32, device=x.device)
+        Ct = w3.shape[0]
+        bn3_, bn1_ = rp.conv3x3._parts()[1], rp.conv1x1._parts()[1]
+        d3, d1 = make_desc(x, w3, 1), make_desc(x, w1, 1)
+        Do, Ho, Wo = desc_out_dims(d3)
+        V = Do * Ho * Wo
+        r3 = torch.empty(_like_spatial(x, Ct, Do, Ho, Wo), **f32)
+        r1 = torch.empty_like(r3)
+        mi3, mi1, miB = (torch.empty(2 * Ct, **f32) for _ in range(3))
+        ch3, ch1, chB = (torch.empty(5 * Ct, **f32) for _ in range(3))
+        _cba_raw(d3, x, None, w3, b3, bn3_, slope, r3, mi3, ch3)
+        _cba_raw(d1, x, None, w1, b1, bn1_, slope, r1, mi1, ch1)
+        t = torch.empty_like(r3)
+        nblk = L.dpi_stat_blocks(Ct, V)
+        part = torch.empty(nblk * Ct * 2, dtype=torch.float64, device=x.device)
+        check(L.dpi_chain_add_stats(ptr(r1), ptr(ch1), ptr(r3), ptr(ch3), Ct, V, slope, ptr(t), ptr(part), stream()),
+              "dpi_chain_add_stats")
+        B = rp.bn
+        raw_bn_finalize(part, nblk, Ct, V, gB, eB, slope, B.running_mean, B.running_var, B.num_batches_tracked, miB, chB,
+                        act_first=1)
+        y = torch.empty_like(t)
+        raw_chain_apply(t, chB, Ct, V, y)
+        ctx.save_for_backward(x, r3, r1, t, mi3, mi1, miB, *[q for q in p if q is not None])
+        ctx.none_mask = [q is None for q in p]
+        ctx.descs = (d3, d1)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _req(dy, "respath grad")
+        x, r3, r1, t, mi3, mi1, miB = ctx.saved_tensors[:7]
+        it = iter(ctx.saved_tensors[7:])
+        (w3, b3, g3, e3, w1, b1, g1, e1, gB, eB) = [None if isnone else next(it) for isnone in ctx.none_mask]
+        d3, d1 = ctx.descs
+        slope = ctx.slope
+        dt, dgB, deB = _bn_backward(dy, t, miB, gB, eB, slope, 1.0)
+        dr3, dg3, de3 = _bn_backward(dt, r3, mi3, g3, e3, 1.0, slope)
+        dr1, dg1, de1 = _bn_backward(dt, r1, mi1, g1, e1, 1.0, slope)
+        del dt
+        dw3, dw1 = torch.empty_like(w3), torch.empty_like(w1)
+        raw_conv_bwd_weight(d3, x, None, dr3, dw3)
+        raw_conv_bwd_weight(d1, x, None, dr1, dw1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            raw_conv_bwd_data(d1, dr1, w1, dx)
+            raw_conv_bwd_data(d3, dr3, w3, dx, accumulate=True)
+        z = _zeros_like_or_none
+        return dx, None, None, dw3, z(b3), dg3, de3, dw1, z(b1), dg1, de1, dgB, deB
 
 
 class LeakyReLUFn(torch.autograd.Function):
@@ -490,6 +671,23 @@ def batch_norm(x, gamma, beta, running_mean=None, running_var=None, nbt=None, sl
 
 def conv_bn_act(x, w, b, gamma, beta, running_mean, running_var, nbt, stride=1, slope=0.2):
     return ConvBnActFn.apply(x, w, b, gamma, beta, running_mean, running_var, nbt, int(stride), float(slope))
+
+
+def _cba_params(m):
+    conv_m, bn, _ = m._parts()
+    return [conv_m.weight, conv_m.bias, bn.weight, bn.bias]
+
+
+def block3d(x, blk, slope):
+    """fused Block3d; `blk` is the MultiResBlock module (parameters are passed explicitly so autograd tracks them)."""
+    p = (_cba_params(blk.conv3x3) + _cba_params(blk.conv5x5) + _cba_params(blk.conv7x7) + _cba_params(blk.shortcut)
+         + [blk.bn1.weight, blk.bn1.bias, blk.bn2.weight, blk.bn2.bias])
+    return Block3dFn.apply(x, blk, slope, *p)
+
+
+def respath3d(x, rp, slope):
+    p = _cba_params(rp.conv3x3) + _cba_params(rp.conv1x1) + [rp.bn.weight, rp.bn.bias]
+    return ResPath3dFn.apply(x, rp, slope, *p)
 
 
 def leaky_relu(x, slope=0.2):

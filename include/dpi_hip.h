@@ -90,10 +90,13 @@ int dpi_channel_stats(const float* x, const float* chain, int C, size_t V, doubl
  * write chain_out[c] = {gamma*invstd, beta - mean*gamma*invstd, slope, 1, 0}  (BN-apply followed by act with
  * `slope`; slope = 1 means no activation) or, with act_first != 0, {1, 0, slope, gamma*invstd, beta - mean*...}
  * (BN of act(x), the partials then being statistics of act(x)).  running_* / nbt / chain_out may be NULL.
+ * in_chain != NULL (requires slope == 1, act_first == 0): the partials are statistics of T_in(x) and chain_out is the
+ * composition BN(T_in(x)) = {in.ps, in.pb, in.slope, a*in.qs, a*in.qb + shift} — bn1 over the never-materialised
+ * concat of Block3d (mulresunet.py:90-91).
  * mean_invstd: float[2][C]. */
 int dpi_bn_finalize(const double* partials, int nblk, int C, size_t count, const float* gamma,
                     const float* beta, float eps, float momentum, float slope, int act_first,
-                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    const float* in_chain, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                     float* mean_invstd, float* chain_out, void* stream);
 /* y = T(x) elementwise */
 int dpi_chain_apply(const float* x, const float* chain, int C, size_t V, float* y, void* stream);
@@ -101,13 +104,20 @@ int dpi_chain_apply(const float* x, const float* chain, int C, size_t V, float* 
  *   pre_slope  (act -> BN, mulresunet.py:93-94,110-111): u = act(x) was normalised; dx = du * act'(x)
  *   post_slope (BN -> act, base.py:214-215):            dy is w.r.t. act(BN(x)); g = dy * act'(gamma*xhat + beta)
  * phase 1: partials[nblk][C][2] = {sum g, sum g*xhat}, xhat = (act_pre(x) - mean) * invstd
- * phase 2: dx = gamma*invstd*(g - sum_g/V - xhat*sum_gxhat/V) * act_pre'(x); dgamma = sum_gxhat; dbeta = sum_g */
+ * phase 2: dx = gamma*invstd*(g - sum_g/V - xhat*sum_gxhat/V) * act_pre'(x); dgamma = sum_gxhat; dbeta = sum_g
+ * in_chain != NULL (requires pre_slope == 1): the normalised tensor was u = T_in(x) (value only) and dx is the
+ * gradient w.r.t. u, not x. */
 int dpi_bn_bwd_reduce(const float* dy, const float* x, const float* mean_invstd, const float* gamma,
-                      const float* beta, float pre_slope, float post_slope, int C, size_t V,
-                      double* partials, void* stream);
+                      const float* beta, const float* in_chain, float pre_slope, float post_slope, int C,
+                      size_t V, double* partials, void* stream);
 int dpi_bn_bwd_apply(const float* dy, const float* x, const float* mean_invstd, const float* gamma,
-                     const float* beta, float pre_slope, float post_slope, const double* partials,
-                     int nblk, int C, size_t V, float* dx, float* dgamma, float* dbeta, void* stream);
+                     const float* beta, const float* in_chain, float pre_slope, float post_slope,
+                     const double* partials, int nblk, int C, size_t V, float* dx, float* dgamma,
+                     float* dbeta, void* stream);
+/* t = T_a(a) + T_b(b);  partials[nblk][C][2] = {sum, sum^2} of act(t) with LeakyReLU(slope): the residual join
+ * followed by act -> BatchNorm of Block3d / ResPath3d (mulresunet.py:92-94,109-111) in one pass. */
+int dpi_chain_add_stats(const float* a, const float* chain_a, const float* b, const float* chain_b, int C,
+                        size_t V, float slope, float* t, double* partials, void* stream);
 /* dx = dy * act'(x) with act(v) = v>0 ? v : slope*v  (x = the activation INPUT or OUTPUT: same sign) */
 int dpi_lrelu_bwd(const float* dy, const float* x, float slope, size_t n, float* dx, void* stream);
 /* y = a + b */
