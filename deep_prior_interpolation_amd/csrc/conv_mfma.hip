@@ -161,6 +161,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MArgs a) {
   float wn[TAPS], sr[4][G::E];
   load_w(wn, 0);
   stage_load<G>(sr, a.x, a.Cin, V, 0, goff);
+  if (a.accumulate) {
+    // gradient fan-in: start the accumulators from the destination (loads overlap the first chunk's staging)
+    const int Do_ = (a.D + 2 * PD - KD) / G::SD + 1, Ho_ = (a.H - 1) / S + 1, Wo_ = (a.W - 1) / S + 1;
+    const size_t Vo_ = (size_t)Do_ * Ho_ * Wo_;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = n0 + 4 * lk + r;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
+        if (co < a.Cout && od < Do_ && oh < Ho_ && ow < Wo_) acc[t][r] = a.y[(size_t)co * Vo_ + ((size_t)od * Ho_ + oh) * Wo_ + ow];
+      }
+    }
+  }
 
   for (int c0 = 0; c0 < a.Cin; c0 += 4) {
     float wr[TAPS];
@@ -220,8 +234,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MArgs a) {
       const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
       if (cok && od < Do && oh < Ho && ow < Wo) {
         float* yp = a.y + (size_t)co * Vo + ((size_t)od * Ho + oh) * Wo + ow;
-        float v = acc[t][r] + bv;
-        if (a.accumulate) v += *yp;
+        const float v = acc[t][r] + bv;
         *yp = v;
         s += v;
         q += (double)v * v;
