@@ -119,8 +119,10 @@ __device__ __forceinline__ void stage_store(float* lds, const float (&sr)[4][G::
 }
 
 // ---------------------------------------------------------------- forward / backward-data ---------------------------
-template <int KD, int NR, int NH, bool FLIP, int S = 1>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(MArgs a) {
+// WPE = waves per SIMD the register allocation is held to: 3 pays when Cin <= 8 (one or two chunks: the staging of a
+// tile is not hidden behind its own MFMAs, only behind other workgroups'), 2 (no cap) is faster for long channel loops.
+template <int KD, int NR, int NH, bool FLIP, int S = 1, int WPE = 1>
+__global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
   using G = Geo<KD, NR, NH, S>;
   constexpr int TAPS = KD * 9;
   constexpr int PD = (KD - 1) / 2;
@@ -150,16 +152,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MArgs a) {
 
   // weights of a 4-channel chunk: lane (co = lj, ci = lk) keeps its TAPS filter taps
   const int co_w = n0 + lj;
-  auto load_w = [&](float (&wr)[TAPS], int c0) {
+  // The taps of depth plane kd are dead once that plane's steps are done, so the NEXT chunk's weights are loaded
+  // straight into the same registers plane by plane (no second register set: 27 VGPRs less -> 3 waves / SIMD).
+  auto load_w = [&](float (&wr)[TAPS], int c0, int t0, int t1) {
     const int ci = c0 + lk;
     const bool ok = co_w < a.Cout && ci < a.Cin;
     const float* __restrict__ wp = a.w + (ok ? co_w : 0) * a.w_out_stride + (ok ? ci : 0) * a.w_in_stride;
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) wr[t] = ok ? wp[FLIP ? (TAPS - 1 - t) : t] : 0.f;
+    for (int t = t0; t < t1; ++t) {
+      const float v = wp[FLIP ? (TAPS - 1 - t) : t];
+      wr[t] = ok ? v : 0.f;
+    }
   };
 
-  float wn[TAPS], sr[4][G::E];
-  load_w(wn, 0);
+  float wr[TAPS], sr[4][G::E];
+  load_w(wr, 0, 0, TAPS);
   stage_load<G>(sr, a.x, a.Cin, V, 0, goff);
   if (a.accumulate) {
     // gradient fan-in: start the accumulators from the destination (loads overlap the first chunk's staging)
@@ -177,16 +184,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MArgs a) {
   }
 
   for (int c0 = 0; c0 < a.Cin; c0 += 4) {
-    float wr[TAPS];
     __syncthreads();                                     // everyone is done reading the previous chunk
     stage_store<G>(lds, sr, a.chain, a.Cin, c0, goff, loff);
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) wr[t] = wn[t];
     __syncthreads();
-    if (c0 + 4 < a.Cin) {                                // prefetch the next chunk behind this chunk's MFMAs
-      load_w(wn, c0 + 4);
-      stage_load<G>(sr, a.x, a.Cin, V, c0 + 4, goff);
-    }
+    const bool more = c0 + 4 < a.Cin;
+    if (more) stage_load<G>(sr, a.x, a.Cin, V, c0 + 4, goff);   // prefetch the next chunk behind this chunk's MFMAs
     // software-pipelined walk over (kd, input row): LDS values of step s+1 are requested before the MFMAs of step s
     float bc[G::NB], bn[G::NB];
     auto load_b = [&](float (&b)[G::NB], int step) {
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MArgs a) {
         }
 #pragma unroll
       for (int i = 0; i < G::NB; ++i) bc[i] = bn[i];
+      if (ir == G::NROW - 1 && more) load_w(wr, c0 + 4, kd * 9, kd * 9 + 9);
     }
   }
 
@@ -682,7 +685,8 @@ static void launch_variant(const MArgs& a, int nr, int nh, int stride, dim3 grid
     }
     return;
   }
-  if (nr == 8) conv_mfma_kernel<KD, 8, 2, FLIP><<<grid, 256, 0, st>>>(a);
+  if (nr == 8 && a.Cin <= 8) conv_mfma_kernel<KD, 8, 2, FLIP, 1, 3><<<grid, 256, 0, st>>>(a);
+  else if (nr == 8) conv_mfma_kernel<KD, 8, 2, FLIP><<<grid, 256, 0, st>>>(a);
   else if (nh == 2) conv_mfma_kernel<KD, 2, 2, FLIP><<<grid, 256, 0, st>>>(a);
   else conv_mfma_kernel<KD, 2, 1, FLIP><<<grid, 256, 0, st>>>(a);
 }
