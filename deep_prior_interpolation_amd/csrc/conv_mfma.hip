@@ -96,11 +96,16 @@ __device__ __forceinline__ void stage_load(float (&sr)[4][G::E], const float* __
                                            const int (&goff)[G::E]) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const int ci = c0 + c;
-    const bool cok = ci < Cin;
-    const float* __restrict__ xc = x + (size_t)(cok ? ci : 0) * V;
+    // channels past Cin re-read the last real channel: their WEIGHTS are zero (load_w), so no uniform branch is needed
+    const int ci = min(c0 + c, Cin - 1);
+    const float* __restrict__ xc = x + (size_t)ci * V;
 #pragma unroll
-    for (int e = 0; e < G::E; ++e) sr[c][e] = (cok && goff[e] >= 0) ? xc[goff[e]] : 0.f;
+    for (int e = 0; e < G::E; ++e) {
+      // unconditional load from a clamped (always valid) address + select: no exec-mask branch per element, so the
+      // loads of a chunk issue back to back and can be scheduled across the MFMA stream
+      const float v = xc[goff[e] >= 0 ? goff[e] : 0];
+      sr[c][e] = goff[e] >= 0 ? v : 0.f;
+    }
   }
 }
 
@@ -110,11 +115,13 @@ __device__ __forceinline__ void stage_store(float* lds, const float (&sr)[4][G::
                                             const int (&goff)[G::E], const int (&loff)[G::E]) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const int ci = c0 + c;
-    const Chain t = load_chain(chain, ci < Cin ? ci : 0);
+    const int ci = min(c0 + c, Cin - 1);
+    const Chain t = load_chain(chain, ci);
 #pragma unroll
-    for (int e = 0; e < G::E; ++e)
-      if (loff[e] >= 0) lds[c * G::CS + loff[e]] = (chain && goff[e] >= 0 && ci < Cin) ? apply_chain(t, sr[c][e]) : sr[c][e];
+    for (int e = 0; e < G::E; ++e) {
+      const float v = (chain && goff[e] >= 0) ? apply_chain(t, sr[c][e]) : sr[c][e];
+      if ((e + 1) * 256 <= G::TILE || loff[e] >= 0) lds[c * G::CS + loff[e]] = v;   // only the last slot can be past the tile
+    }
   }
 }
 
