@@ -29,7 +29,7 @@ FLOP_PER_VOXEL_ITER = 1712.6e9 / (256 * 128 * 128)
 FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak (nominal, 2.4 GHz)
 # calibration on the box: the dominant kernel with staging and LDS reads compiled out (pure
 # v_mfma_f32_16x16x4_f32 stream) sustains 107.8 TFLOP/s on this shape = 120.8 TFLOP/s of MFMA issue (clock ~1.85 GHz under load)
-FP32_SUSTAINED_TFLOPS = 120.8
+FP32_SUSTAINED_TFLOPS = 154.0   # tools/ubench/mfma_rate: pure v_mfma_f32_16x16x4_f32 stream, 32.25 clk/MFMA at 2.39 GHz
 HBM_PEAK_GBS = 8000.0
 
 

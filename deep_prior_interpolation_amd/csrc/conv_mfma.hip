@@ -128,8 +128,25 @@ __device__ __forceinline__ void stage_store(float* lds, const float (&sr)[4][G::
 // ---------------------------------------------------------------- forward / backward-data ---------------------------
 // WPE = waves per SIMD the register allocation is held to: 3 pays when Cin <= 8 (one or two chunks: the staging of a
 // tile is not hidden behind its own MFMAs, only behind other workgroups'), 2 (no cap) is faster for long channel loops.
-template <int KD, int NR, int NH, bool FLIP, int S = 1, int WPE = 1>
+#ifdef DPI_TRACE
+__device__ long long g_blk[8192][4];
+__device__ long long g_trace[4][64];
+#define TR(i) do { if (trc >= 0 && tid == 0) g_trace[trc][i] = clock64(); } while (0)
+#else
+#define TR(i)
+#endif
+template <int KD, int NR, int NH, bool FLIP, int S = 1, int WPE = 2>
 __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
+#ifdef DPI_TRACE
+  const int trc = blockIdx.y != 0 ? -1 : blockIdx.x == 0 ? 0 : blockIdx.x == 1 ? 1 : blockIdx.x == 2048 ? 2 : blockIdx.x == 4000 ? 3 : -1;
+  const int tid_ = threadIdx.x;
+  { const int tid = tid_; TR(0); }
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) {
+    g_blk[blockIdx.x][0] = wall_clock64();
+    g_blk[blockIdx.x][2] = __builtin_amdgcn_s_getreg(63492);
+    g_blk[blockIdx.x][3] = __builtin_amdgcn_s_getreg(63508);
+  }
+#endif
   using G = Geo<KD, NR, NH, S>;
   constexpr int TAPS = KD * 9;
   constexpr int PD = (KD - 1) / 2;
@@ -157,24 +174,38 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // weights of a 4-channel chunk: lane (co = lj, ci = lk) keeps its TAPS filter taps
+  // weights of a 4-channel chunk: lane (co = lj, ci = lk) keeps its TAPS filter taps.
+  // The taps of depth plane kd are dead once that plane's steps are done, so the NEXT chunk's weights replace them plane
+  // by plane: requested (raw, from a clamped address) into 9 staging registers when the plane starts, selected into
+  // place when it ends — a whole plane of MFMAs hides the load, and no second 27-register set is needed.
   const int co_w = n0 + lj;
-  // The taps of depth plane kd are dead once that plane's steps are done, so the NEXT chunk's weights are loaded
-  // straight into the same registers plane by plane (no second register set: 27 VGPRs less -> 3 waves / SIMD).
-  auto load_w = [&](float (&wr)[TAPS], int c0, int t0, int t1) {
+  auto w_ptr = [&](int c0, bool& ok) {
     const int ci = c0 + lk;
-    const bool ok = co_w < a.Cout && ci < a.Cin;
-    const float* __restrict__ wp = a.w + (ok ? co_w : 0) * a.w_out_stride + (ok ? ci : 0) * a.w_in_stride;
+    ok = co_w < a.Cout && ci < a.Cin;
+    return a.w + (ok ? co_w : 0) * a.w_out_stride + (ok ? ci : 0) * a.w_in_stride;
+  };
+  auto load_w_raw = [&](float (&wn)[9], int c0, int kd) {
+    bool ok;
+    const float* __restrict__ wp = w_ptr(c0, ok);
 #pragma unroll
-    for (int t = t0; t < t1; ++t) {
-      const float v = wp[FLIP ? (TAPS - 1 - t) : t];
-      wr[t] = ok ? v : 0.f;
-    }
+    for (int t = 0; t < 9; ++t) wn[t] = wp[FLIP ? (TAPS - 1 - (kd * 9 + t)) : kd * 9 + t];
+  };
+  auto commit_w = [&](float (&wr)[TAPS], const float (&wn)[9], int c0, int kd) {
+    const bool ok = co_w < a.Cout && c0 + lk < a.Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[kd * 9 + t] = ok ? wn[t] : 0.f;
   };
 
-  float wr[TAPS], sr[4][G::E];
-  load_w(wr, 0, 0, TAPS);
+  float wr[TAPS], wn[9], sr[4][G::E];
   stage_load<G>(sr, a.x, a.Cin, V, 0, goff);
+  {
+    bool ok;
+    const float* __restrict__ wp = w_ptr(0, ok);
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) wr[t] = wp[FLIP ? (TAPS - 1 - t) : t];     // all in flight together
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) wr[t] = ok ? wr[t] : 0.f;
+  }
   if (a.accumulate) {
     // gradient fan-in: start the accumulators from the destination (loads overlap the first chunk's staging)
     const int Do_ = (a.D + 2 * PD - KD) / G::SD + 1, Ho_ = (a.H - 1) / S + 1, Wo_ = (a.W - 1) / S + 1;
@@ -190,10 +221,14 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
     }
   }
 
+  TR(1);
   for (int c0 = 0; c0 < a.Cin; c0 += 4) {
     __syncthreads();                                     // everyone is done reading the previous chunk
+    TR(2 + (c0 / 4) * 4);
     stage_store<G>(lds, sr, a.chain, a.Cin, c0, goff, loff);
+    TR(3 + (c0 / 4) * 4);
     __syncthreads();
+    TR(4 + (c0 / 4) * 4);
     const bool more = c0 + 4 < a.Cin;
     if (more) stage_load<G>(sr, a.x, a.Cin, V, c0 + 4, goff);   // prefetch the next chunk behind this chunk's MFMAs
     // software-pipelined walk over (kd, input row): LDS values of step s+1 are requested before the MFMAs of step s
@@ -206,10 +241,15 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
         for (int kw = 0; kw < 3; ++kw) b[h * 3 + kw] = lds[lbase + kd * G::DS + ir * G::RS + h * 16 * S + kw];
     };
     load_b(bc, 0);
+    const int cn = more ? c0 + 4 : c0;                   // chunk whose weights are fetched next (a harmless re-read at the end)
 #pragma unroll
     for (int step = 0; step < G::NSTEP; ++step) {
-      if (step + 1 < G::NSTEP) load_b(bn, step + 1);
       const int kd = step / G::NROW, ir = step % G::NROW;
+      if (step + 1 < G::NSTEP) load_b(bn, step + 1);
+      if (ir == 0) load_w_raw(wn, cn, kd);
+      // keep the requests above AHEAD of this step's MFMAs (the scheduler otherwise sinks every ds_read to just before
+      // its first use and the wave then waits out the full LDS latency ~27 times per chunk)
+      if (WPE <= 2) __builtin_amdgcn_sched_barrier(0);
       // kw outermost: consecutive MFMAs go to DIFFERENT accumulators (a dependent 16x16x4 f32 MFMA needs 40 cycles,
       // an independent one issues every 32)
 #pragma unroll
@@ -223,31 +263,46 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
               acc[hr * NH + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(kd * 3 + kh) * 3 + kw], bc[h * 3 + kw], acc[hr * NH + h], 0, 0, 0);
           }
         }
+      if (WPE <= 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < G::NB; ++i) bc[i] = bn[i];
-      if (ir == G::NROW - 1 && more) load_w(wr, c0 + 4, kd * 9, kd * 9 + 9);
+      if (ir == G::NROW - 1) commit_w(wr, wn, cn, kd);
     }
+    TR(5 + (c0 / 4) * 4);
   }
+  TR(40);
 
   // ---- epilogue: D row = co (4*lk + r), D col = voxel lj -----------------------------------------------------------
   const int Do = (a.D + 2 * PD - KD) / G::SD + 1, Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
   const size_t Vo = (size_t)Do * Ho * Wo;
   __shared__ double red[4][16][2];
+  // interior tile with a full channel tile (the common case): no per-element bounds tests, one base pointer per row r
+  const bool interior = od0 + G::TZ <= Do && oh0 + G::TY <= Ho && ow0 + G::TW <= Wo && n0 + 16 <= a.Cout;
+  const int vbase = ((od0 + wz) * Ho + oh0 + wh) * Wo + ow0 + lj;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int co = n0 + 4 * lk + r;
     const bool cok = co < a.Cout;
     const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
+    float* __restrict__ yc = a.y + (size_t)(cok ? co : 0) * Vo + vbase;
     double s = 0.0, q = 0.0;
+    if (interior) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
-      if (cok && od < Do && oh < Ho && ow < Wo) {
-        float* yp = a.y + (size_t)co * Vo + ((size_t)od * Ho + oh) * Wo + ow;
+      for (int t = 0; t < NT; ++t) {
         const float v = acc[t][r] + bv;
-        *yp = v;
-        s += v;
-        q += (double)v * v;
+        yc[(t / NH) * Wo + (t % NH) * 16] = v;
+        if (a.partials) { s += v; q += (double)v * v; }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
+        if (cok && od < Do && oh < Ho && ow < Wo) {
+          const float v = acc[t][r] + bv;
+          yc[(t / NH) * Wo + (t % NH) * 16] = v;
+          s += v;
+          q += (double)v * v;
+        }
       }
     }
     if (a.partials) {
@@ -264,6 +319,10 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
       if (n0 + c < a.Cout) a.partials[((size_t)tile_id * a.Cout + n0 + c) * 2 + which] = rsum;
     }
   }
+  TR(41);
+#ifdef DPI_TRACE
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) g_blk[blockIdx.x][1] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------- backward-weight ----------------------------------
@@ -698,6 +757,10 @@ static void launch_variant(const MArgs& a, int nr, int nh, int stride, dim3 grid
   else conv_mfma_kernel<KD, 2, 1, FLIP><<<grid, 256, 0, st>>>(a);
 }
 
+#ifdef DPI_TRACE
+extern "C" int dpi_debug_read_blocks(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk), sizeof(long long) * 8192 * 4); }
+extern "C" int dpi_debug_read_trace(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(long long) * 4 * 64); }
+#endif
 int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
                       double* partials, bool flip, int accumulate, hipStream_t st) {
   const int taps = d->kd * 9;
