@@ -64,36 +64,48 @@ __global__ __launch_bounds__(256) void conv_pw_mfma_kernel(PwMArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[m][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const int ci = ch * 4 + lk;
-      const bool cok = ci < a.Cin;
-      float b[4] = {0.f, 0.f, 0.f, 0.f};
-      if (cok) {
-        const float* __restrict__ xp = a.x + (size_t)ci * a.V + v0;
-        if (vec && v0 + 3 < a.V) {
-          const float4 f = *reinterpret_cast<const float4*>(xp);
-          b[0] = f.x; b[1] = f.y; b[2] = f.z; b[3] = f.w;
+    // channel chunks in batches of PF: all loads of a batch are in flight before its first MFMA (branch-free: clamped
+    // channel / address + select), so a wave keeps PF KB outstanding instead of one
+    constexpr int PF = 8;
+    const bool full4 = vec && v0 + 3 < a.V;
+    for (int cb = 0; cb < nchunk; cb += PF) {
+      float b[PF][4];
+#pragma unroll
+      for (int p = 0; p < PF; ++p) {
+        const int ci = min((cb + p) * 4 + lk, a.Cin - 1);       // past Cin: re-read the last channel, weights are zero
+        const float* __restrict__ xp = a.x + (size_t)ci * a.V;
+        if (full4) {
+          const float4 f = *reinterpret_cast<const float4*>(xp + v0);
+          b[p][0] = f.x; b[p][1] = f.y; b[p][2] = f.z; b[p][3] = f.w;
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) b[e] = v0 + e < a.V ? xp[e] : 0.f;
-        }
-        if (a.chain) {
-          const Chain t = load_chain(a.chain, ci);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) b[e] = apply_chain(t, b[e]);
+          for (int e = 0; e < 4; ++e) { const float v = xp[v0 + e < a.V ? v0 + e : 0]; b[p][e] = v0 + e < a.V ? v : 0.f; }
         }
       }
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        float wv;
-        if constexpr (WLDS) wv = wl[(ch * MT + m) * 64 + lane];
-        else {
-          const int co = n0 + m * 16 + lj;
-          wv = (cok && co < a.Cout) ? a.w[co * a.w_out_stride + ci * a.w_in_stride] : 0.f;
-        }
+      for (int p = 0; p < PF; ++p) {
+        const int ch = cb + p;
+        if (ch < nchunk) {
+          const int ci = ch * 4 + lk;
+          const bool cok = ci < a.Cin;
+          if (a.chain) {
+            const Chain t = load_chain(a.chain, min(ci, a.Cin - 1));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[m][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, b[e], acc[m][e], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) b[p][e] = apply_chain(t, b[p][e]);
+          }
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            float wv;
+            if constexpr (WLDS) wv = wl[(ch * MT + m) * 64 + lane];
+            else {
+              const int co = n0 + m * 16 + lj;
+              const float wraw = a.w[(co < a.Cout ? co : 0) * a.w_out_stride + (cok ? ci : 0) * a.w_in_stride];
+              wv = (cok && co < a.Cout) ? wraw : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[m][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, b[p][e], acc[m][e], 0, 0, 0);
+          }
+        }
       }
     }
     // D row = co (4*lk + r), D col lj of tile e = voxel v0 + e
