@@ -436,6 +436,7 @@ int check_desc(const dpi_conv_desc* d) {
 // MFMA stencil path (conv_mfma.hip): k = 3, stride 1, enough output channels to fill a 16-row MFMA tile
 int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
                       double* partials, bool flip, int accumulate, hipStream_t st);
+void dpi_conv_pw_mfma_plan(size_t V, int cout, int* vox_per_block, int* mt);
 int dpi_conv_pw_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
                          double* partials, bool flip, int accumulate, hipStream_t st);
 int dpi_conv_bwd_data_s2_mfma_run(const dpi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, hipStream_t st);
@@ -455,6 +456,11 @@ extern "C" int dpi_conv_fwd_stat_blocks(const dpi_conv_desc* d) {
   if (check_desc(d) != DPI_OK) return 0;
   int Do, Ho, Wo;
   dpi_conv_out_dims(d, &Do, &Ho, &Wo);
+  if (d->k == 1 && d->Cout >= g_mfma_min_cout) {
+    int vpb, mt;
+    dpi_conv_pw_mfma_plan((size_t)Do * Ho * Wo, d->Cout, &vpb, &mt);
+    return (int)cdivz((size_t)Do * Ho * Wo, vpb);
+  }
   if (d->k == 1) return (int)cdivz((size_t)Do * Ho * Wo, 1024);
   if (d->k == 3 && d->Cout >= g_mfma_min_cout) {
     int nr, nh, a, b, c;

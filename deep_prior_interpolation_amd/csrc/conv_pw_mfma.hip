@@ -27,6 +27,7 @@ struct PwMArgs {
   size_t V;
   long w_out_stride, w_in_stride;
   int accumulate;
+  int gpb;                  // 64-voxel groups per workgroup: 16 (1024 voxels) or 4 (256 voxels, coarse levels)
 };
 
 // block = 4 waves = 1024 voxels (wave w takes 64-voxel groups w, w+4, w+8, w+12); MT cout tiles per block.
@@ -56,9 +57,10 @@ __global__ __launch_bounds__(256) void conv_pw_mfma_kernel(PwMArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ssum[m][r] = 0.0; qsum[m][r] = 0.0; }
 
-  for (int grp = wid; grp < 16; grp += 4) {
-    const size_t v0 = (size_t)blockIdx.x * 1024 + (size_t)grp * 64 + 4 * lj;
-    if ((size_t)blockIdx.x * 1024 + (size_t)grp * 64 >= a.V) break;
+  for (int grp = wid; grp < a.gpb; grp += 4) {
+    const size_t g0 = ((size_t)blockIdx.x * a.gpb + grp) * 64;
+    const size_t v0 = g0 + 4 * lj;
+    if (g0 >= a.V) break;
     f32x4 acc[MT][4];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -188,37 +190,42 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_weight_mfma_kernel(PwBwArgs a
 
   const size_t vbeg = (size_t)blockIdx.x * a.vox_per_chunk;
   const size_t vend = vbeg + a.vox_per_chunk < a.V ? vbeg + a.vox_per_chunk : a.V;
-  for (size_t g0 = vbeg + (size_t)wid * 16; g0 < vend; g0 += 64) {
-    const size_t v0 = g0 + 4 * lk;
-    float ga[MT][4], xb[NT][4];
-    auto load4 = [&](const float* __restrict__ p, float (&o)[4]) {
-      if (vec && v0 + 3 < vend) {
-        const float4 f = *reinterpret_cast<const float4*>(p);
-        o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = f.w;
+  // A wave takes 64 voxels per round: lane (row lj, k = lk) owns voxels g0 + 16*lk + [0,16) -> four consecutive float4
+  // per operand row (64 B per lane, 256 B contiguous per channel), all requested before the first MFMA of the round.
+  // Rows past Cout / Cin re-read the last real channel (their products land in rows that are never written).
+  const float* __restrict__ dyr[MT];
+  const float* __restrict__ xr[NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) dyr[m] = a.dy + (size_t)min(co0 + m * 16 + lj, a.Cout - 1) * a.V;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) xr[n] = a.x + (size_t)min(ci0 + n * 16 + lj, a.Cin - 1) * a.V;
+  for (size_t g0 = vbeg + (size_t)wid * 64; g0 < vend; g0 += 256) {
+    const size_t v0 = g0 + 16 * lk;
+    float ga[MT][16], xb[NT][16];
+    auto load16 = [&](const float* __restrict__ p, float (&o)[16]) {
+      if (vec && v0 + 15 < vend) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 f = *reinterpret_cast<const float4*>(p + v0 + 4 * j);
+          o[4 * j] = f.x; o[4 * j + 1] = f.y; o[4 * j + 2] = f.z; o[4 * j + 3] = f.w;
+        }
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = v0 + e < vend ? p[e] : 0.f;
+        for (int e = 0; e < 16; ++e) { const float v = p[v0 + e < vend ? v0 + e : vbeg]; o[e] = v0 + e < vend ? v : 0.f; }
       }
     };
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int co = co0 + m * 16 + lj;
-      if (co < a.Cout) load4(a.dy + (size_t)co * a.V + v0, ga[m]);
-      else { ga[m][0] = ga[m][1] = ga[m][2] = ga[m][3] = 0.f; }
+    for (int m = 0; m < MT; ++m) load16(dyr[m], ga[m]);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) load16(xr[n], xb[n]);
+    if (a.chain) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xb[n][e] = (v0 + e < vend) ? apply_chain(ch[n], xb[n][e]) : 0.f;
     }
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int ci = ci0 + n * 16 + lj;
-      if (ci < a.Cin) {
-        load4(a.x + (size_t)ci * a.V + v0, xb[n]);
-        if (a.chain) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xb[n][e] = (v0 + e < vend) ? apply_chain(ch[n], xb[n][e]) : 0.f;
-        }
-      } else { xb[n][0] = xb[n][1] = xb[n][2] = xb[n][3] = 0.f; }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < 16; ++e)
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -274,13 +281,30 @@ PwBwPlan pw_bw_plan(const dpi_conv_desc* d) {
 
 }  // namespace
 
+// Work split of the pointwise MFMA kernel: (voxels per workgroup, 16-channel tiles per workgroup).  The fine levels use
+// 1024 voxels x up to 64 output channels (the input tile is read once for all of them); the coarse levels of the U-Net
+// (a few thousand voxels, hundreds of channels) would leave most CUs idle that way, so they get 256-voxel workgroups
+// and, if that is still not ~4 waves per CU, one channel tile per workgroup.
+void dpi_conv_pw_mfma_plan(size_t V, int cout, int* vox_per_block, int* mt) {
+  int m = cout <= 16 ? 1 : (cout <= 32 ? 2 : 4);
+  int vpb = 1024;
+  auto waves = [&]() { return (long)cdivz(V, vpb) * (vpb / 256) * cdiv(cout, 16 * m); };
+  if (waves() < 1024) vpb = 256;
+  if (waves() < 1024 && m == 4) m = 2;
+  if (waves() < 1024 && m == 2) m = 1;
+  *vox_per_block = vpb;
+  *mt = m;
+}
+
 int dpi_conv_pw_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
                          double* partials, bool flip, int accumulate, hipStream_t st) {
   const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
   const long w_out = flip ? 1 : (long)d->Cin, w_in = flip ? (long)d->Cin : 1;
-  PwMArgs a{x, chain, w, bias, y, partials, cin, cout, (size_t)d->D * d->H * d->W, w_out, w_in, accumulate};
-  const unsigned gx = (unsigned)cdivz(a.V, 1024);
-  const int mt = cout <= 16 ? 1 : (cout <= 32 ? 2 : 4);
+  int vpb, mt;
+  PwMArgs a{x, chain, w, bias, y, partials, cin, cout, (size_t)d->D * d->H * d->W, w_out, w_in, accumulate, 0};
+  dpi_conv_pw_mfma_plan(a.V, cout, &vpb, &mt);
+  a.gpb = vpb / 64;
+  const unsigned gx = (unsigned)cdivz(a.V, vpb);
   const bool wlds = (long)cdiv(cin, 4) * mt * 64 <= kPwLdsFloats;
   const dim3 grid(gx, cdiv(cout, 16 * mt));
   if (mt == 1) { if (wlds) conv_pw_mfma_kernel<1, true><<<grid, 256, 0, st>>>(a); else conv_pw_mfma_kernel<1, false><<<grid, 256, 0, st>>>(a); }
