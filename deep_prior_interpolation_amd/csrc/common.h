@@ -41,6 +41,17 @@ __device__ __forceinline__ float apply_chain(const Chain& t, float x) {
   return fmaf(t.qs, v, t.qb);
 }
 
+// ---- raw buffer loads ------------------------------------------------------------------------------
+// A buffer load whose byte offset is >= num_records returns 0 in hardware (checked per dword; verified on gfx950 by
+// tools/ubench/buf_oob.hip).  Zero padding and ragged tile edges therefore need no branch, no select and no 64-bit
+// address arithmetic: the per-lane offset is a 32-bit VGPR, "outside" is any negative offset.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dpi_buffer(const void* base, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes > 0xfffffffcull ? (int)0xfffffffc : (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float dpi_buffer_load(__amdgpu_buffer_rsrc_t r, int byte_offset) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_offset, 0, 0));
+}
+
 // ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -25,7 +25,10 @@ static bool bw_use_smallco(const dpi_conv_desc* d) {
 }
 static int g_bw_mfma_min_cout = 8;
 extern "C" void dpi_set_bwd_weight_mfma_min_cout(int n) { g_bw_mfma_min_cout = n; }
-static bool bw_use_mfma(const dpi_conv_desc* d) { return d->k == 3 && d->Cout >= g_bw_mfma_min_cout; }
+// the MFMA kernel addresses 16 dY channels through one 32-bit buffer offset: 16 * Vo * 4 bytes must stay below 2^31
+static bool bw_use_mfma(const dpi_conv_desc* d) {
+  return d->k == 3 && d->Cout >= g_bw_mfma_min_cout && (size_t)d->D * d->H * d->W < ((size_t)1 << 25);
+}
 
 namespace {
 

@@ -90,7 +90,8 @@ __device__ __forceinline__ void tile_slots(int tid, int id0, int ih0, int iw0, i
   }
 }
 
-// issue the global loads of 4 channels [c0, c0+4) of the halo tile into registers (no wait here)
+// issue the global loads of 4 channels [c0, c0+4) of the halo tile into registers (no wait here).  Buffer loads: slots
+// outside the volume carry goff = -1 -> byte offset -4 -> out of range -> 0 from the hardware (the zero padding).
 template <class G>
 __device__ __forceinline__ void stage_load(float (&sr)[4][G::E], const float* __restrict__ x, int Cin, size_t V, int c0,
                                            const int (&goff)[G::E]) {
@@ -98,14 +99,9 @@ __device__ __forceinline__ void stage_load(float (&sr)[4][G::E], const float* __
   for (int c = 0; c < 4; ++c) {
     // channels past Cin re-read the last real channel: their WEIGHTS are zero (load_w), so no uniform branch is needed
     const int ci = min(c0 + c, Cin - 1);
-    const float* __restrict__ xc = x + (size_t)ci * V;
+    const __amdgpu_buffer_rsrc_t r = dpi_buffer(x + (size_t)ci * V, V * sizeof(float));
 #pragma unroll
-    for (int e = 0; e < G::E; ++e) {
-      // unconditional load from a clamped (always valid) address + select: no exec-mask branch per element, so the
-      // loads of a chunk issue back to back and can be scheduled across the MFMA stream
-      const float v = xc[goff[e] >= 0 ? goff[e] : 0];
-      sr[c][e] = goff[e] >= 0 ? v : 0.f;
-    }
+    for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_buffer_load(r, goff[e] * 4);
   }
 }
 
@@ -342,6 +338,14 @@ struct BwMArgs {
 
 template <int KD, int S, int NR, int NH>
 __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
+#ifdef DPI_TRACE
+  const int trc = (blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 4) ? (int)blockIdx.x : -1;
+  int trn = 0;
+#define TRW() do { if (trc >= 0 && threadIdx.x == 0 && trn < 64) g_trace[trc][trn++] = clock64(); } while (0)
+#else
+#define TRW()
+#endif
+  TRW();
   using G = Geo<KD, NR, NH, S>;
   constexpr int TAPS = KD * 9;
   constexpr int PD = (KD - 1) / 2;
@@ -349,10 +353,15 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
   constexpr int NTQ = (NQ + 15) / 16;         // MFMA column tiles: 7 (96 % full) / 3 (75 %)
   constexpr int KS = 4 * NH;                  // k-steps (4 voxels each) per output row
   constexpr int LDSF = 4 * G::CS > 4 * NTQ * 256 ? 4 * G::CS : 4 * NTQ * 256;
+  constexpr int JP = KS / 4;                  // float4 pieces of a dY row each lane fetches (16 channels x KS pieces / 64 lanes)
+  constexpr int DYRS = 4 * KS + 4;            // row stride of the dY transpose buffer: = 4 (mod 32) -> 2-pass reads
   __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  __shared__ __attribute__((aligned(16))) float dyl[4][16 * DYRS];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lk = lane >> 4, lj = lane & 15;
+  const int wch = lane >> 2, wp = lane & 3;   // dY fetch mapping: channel, float4 piece
+  float* __restrict__ dyw = dyl[wid];
   const int c0 = blockIdx.y * 4, n0 = blockIdx.z * 16;
   const size_t V = (size_t)a.D * a.H * a.W;
   const int Do = (a.D + 2 * PD - KD) / G::SD + 1, Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
@@ -370,9 +379,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
     toff[t] = c * G::CS + kd * G::DS + kh * G::RS + kw;
   }
   const int lbase = wz * G::SD * G::DS + wh * S * G::RS + lk * S;
-  const int co_a = n0 + lj;
-  const bool co_ok = co_a < a.Cout;
-  const float* __restrict__ dyc = a.dy + (size_t)(co_ok ? co_a : 0) * Vo;
+  const __amdgpu_buffer_rsrc_t dyb = dpi_buffer(a.dy + (size_t)n0 * Vo, (size_t)min(16, a.Cout - n0) * Vo * sizeof(float));
 
   f32x4 acc[NTQ];
 #pragma unroll
@@ -395,40 +402,66 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
     stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
   }
   for (int tile = t_begin; tile < t_end; ++tile) {
+    TRW();
     __syncthreads();
+    TRW();
     stage_store<G>(lds, sr, a.chain, a.Cin, c0, goff, loff);
     __syncthreads();
+    TRW();
     const int cod = od0 + wz, coh0 = oh0 + wh, cow0 = ow0;
-    auto load_g = [&](float (&g)[KS], int hr) {
+    // dY rows reach the MFMA A layout (lane = (co, voxel 4s + lk)) through a wave-private LDS transpose: read straight
+    // from global memory that layout makes every load touch 16 channels x 16 B (the L1 / address path, not the matrix
+    // pipe, then bounds the kernel: measured 60 -> 86 TFLOP/s with the loads collapsed onto one channel).  Here each lane
+    // fetches whole float4 pieces (lane -> channel l>>2, piece l&3 [+4]: 64 B contiguous per channel and instruction).
+    auto load_raw = [&](f32x4 (&raw)[JP], int hr) {
       const int oh = coh0 + hr;
-      const bool row_ok = co_ok && cod < Do && oh < Ho;
-      const size_t rbase = ((size_t)cod * Ho + oh) * Wo;
+      const bool row_ok = n0 + wch < a.Cout && cod < Do && oh < Ho;
+      const int base = wch * (int)Vo + (cod * Ho + oh) * Wo + cow0;       // host guarantees 16 * Vo * 4 < 2^31
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int ow = cow0 + 4 * s + lk;
-        g[s] = (row_ok && ow < Wo) ? dyc[rbase + ow] : 0.f;
+      for (int j = 0; j < JP; ++j) {
+        const int p4 = 4 * (wp + 4 * j);
+        raw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyb, (row_ok && cow0 + p4 < Wo) ? (base + p4) * 4 : -16, 0, 0));
       }
     };
-    // vmcnt retires in order: dy rows requested AFTER the next tile's prefetch would make their first use wait for the
+    auto put_row = [&](const f32x4 (&raw)[JP]) {
+#pragma unroll
+      for (int j = 0; j < JP; ++j) {
+        const int p4 = 4 * (wp + 4 * j);
+        f32x4 v = raw[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = cow0 + p4 + e < Wo ? v[e] : 0.f;   // columns past the row end belong to the next row
+        *reinterpret_cast<f32x4*>(dyw + wch * DYRS + p4) = v;
+      }
+    };
+    auto get_row = [&](float (&g)[KS]) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) g[s] = dyw[lj * DYRS + 4 * s + lk];
+    };
+    // vmcnt retires in order: rows requested AFTER the next tile's prefetch would make their first use wait for the
     // whole prefetch.  So the first rows are requested before it, later rows two rows ahead of their use.
     constexpr int NPRE = NR < 4 ? NR : 4;
-    float g[NR][KS];
+    f32x4 raw[NR][JP];
 #pragma unroll
-    for (int hr = 0; hr < NPRE; ++hr) load_g(g[hr], hr);
+    for (int hr = 0; hr < NPRE; ++hr) load_raw(raw[hr], hr);
     if (tile + 1 < t_end) {                                  // prefetch the next tile behind this tile's MFMAs
       tile_origin(tile + 1, od0, oh0, ow0);
       tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
       stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
     }
+    TRW();
+    put_row(raw[0]);
 #pragma unroll
     for (int hr = 0; hr < NR; ++hr) {
-      if (hr >= 2 && hr + 2 < NR && hr + 2 >= NPRE) load_g(g[hr + 2], hr + 2);
+      if (hr >= 2 && hr + 2 < NR && hr + 2 >= NPRE) load_raw(raw[hr + 2], hr + 2);
+      float g[KS];
+      get_row(g);
+      if (hr + 1 < NR) put_row(raw[hr + 1]);                 // LDS ops of a wave execute in order: safe after the reads above
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) {
           const float b = lds[lbase + hr * S * G::RS + 4 * s * S + toff[t]];
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[hr][s], b, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[s], b, acc[t], 0, 0, 0);
         }
       }
     }
