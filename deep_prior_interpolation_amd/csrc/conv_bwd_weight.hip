@@ -21,7 +21,8 @@ size_t dpi_conv_bwd_weight_smallco_ws_floats(const dpi_conv_desc* d);
 int dpi_conv_bwd_weight_smallco_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws,
                                     hipStream_t st);
 static bool bw_use_smallco(const dpi_conv_desc* d) {
-  return d->k == 3 && d->kd == 3 && d->stride == 1 && d->Cout <= 5 && (size_t)d->D * d->H * d->W >= 32768;
+  return d->k == 3 && d->kd == 3 && d->stride == 1 && d->Cout <= 5 && (size_t)d->D * d->H * d->W >= 32768 &&
+         (size_t)d->D * d->H * d->W < ((size_t)1 << 26);   // one 32-bit buffer offset spans the (<= 5) dY channels
 }
 static int g_bw_mfma_min_cout = 8;
 extern "C" void dpi_set_bwd_weight_mfma_min_cout(int n) { g_bw_mfma_min_cout = n; }

@@ -525,7 +525,15 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_smallco_kernel(BwSArgs a)
   }
   const int bco = lj / 3, bkw = lj % 3;
   const bool bok = bco < a.Cout && lj < 15;
-  const float* __restrict__ dyc = a.dy + (size_t)(bok ? bco : 0) * V;
+  // dY rows go through a wave-private LDS row buffer (coalesced float4 fetch, see conv_bwd_weight_mfma_kernel):
+  // [5 channels][4 zeros | 32 voxels | 8 zeros]; the shifted / out-of-tile columns of the B operand read the zero margins.
+  constexpr int DYRS = 44;
+  __shared__ __attribute__((aligned(16))) float dyl[4][5 * DYRS];
+  float* __restrict__ dyw = dyl[wid];
+  for (int i = lane; i < 5 * DYRS; i += 64) dyw[i] = 0.f;
+  const __amdgpu_buffer_rsrc_t dyb = dpi_buffer(a.dy, (size_t)a.Cout * V * sizeof(float));   // Cout <= 5: host keeps 5*V*4 < 2^31
+  const int wch = lane >> 3, wp4 = 4 * (lane & 7);         // fetch mapping: channel, first voxel of the float4 piece
+  const int boff = bok ? bco * DYRS + 4 + lk - bkw : 0;    // B operand: voxel 4s + lk - kw of channel co (index 0 is a zero)
 
   f32x4 acc[4];
 #pragma unroll
@@ -551,14 +559,12 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_smallco_kernel(BwSArgs a)
       loff[e] = idx < TILE ? (dz * IH + hy) * RS + col : -1;
     }
   };
-  auto gload = [&]() {
-#pragma unroll
+  auto gload = [&]() {                                   // buffer loads: goff = -1 (outside the volume) -> 0; channels past
+#pragma unroll                                           // Cin re-read the last one (their rows of dW are never written)
     for (int c = 0; c < CB; ++c) {
-      const int ci = c0 + c;
-      const bool cok = ci < a.Cin;
-      const float* __restrict__ xc = a.x + (size_t)(cok ? ci : 0) * V;
+      const __amdgpu_buffer_rsrc_t r = dpi_buffer(a.x + (size_t)min(c0 + c, a.Cin - 1) * V, V * sizeof(float));
 #pragma unroll
-      for (int e = 0; e < E; ++e) sr[c][e] = (cok && goff[e] >= 0) ? xc[goff[e]] : 0.f;
+      for (int e = 0; e < E; ++e) sr[c][e] = dpi_buffer_load(r, goff[e] * 4);
     }
   };
   int od0 = 0, oh0 = 0, ow0 = 0;
@@ -567,32 +573,43 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_smallco_kernel(BwSArgs a)
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < CB; ++c) {
-      const int ci = c0 + c;
-      const Chain t = load_chain(a.chain, ci < a.Cin ? ci : 0);
+      const Chain t = load_chain(a.chain, min(c0 + c, a.Cin - 1));
 #pragma unroll
-      for (int e = 0; e < E; ++e)
-        if (loff[e] >= 0) lds[c * CS + loff[e]] = (a.chain && goff[e] >= 0 && ci < a.Cin) ? apply_chain(t, sr[c][e]) : sr[c][e];
+      for (int e = 0; e < E; ++e) {
+        const float v = goff[e] >= 0 ? apply_chain(t, sr[c][e]) : sr[c][e];
+        if ((e + 1) * 256 <= TILE || loff[e] >= 0) lds[c * CS + loff[e]] = v;
+      }
     }
     __syncthreads();
     const int cod = od0 + wid, coh0 = oh0, cow0 = ow0;
+    auto load_raw = [&](int hr) {
+      const int oh = coh0 + hr;
+      const bool ok = wch < a.Cout && cod < a.D && oh < a.H && cow0 + wp4 < a.W;
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          dyb, ok ? (wch * (int)V + (cod * a.H + oh) * a.W + cow0 + wp4) * 4 : -16, 0, 0));
+    };
+    auto put_row = [&](f32x4 v) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = cow0 + wp4 + e < a.W ? v[e] : 0.f;
+      if (wch < 5) *reinterpret_cast<f32x4*>(dyw + wch * DYRS + 4 + wp4) = v;
+    };
+    auto get_row = [&](float (&g)[9]) {
+#pragma unroll
+      for (int s = 0; s < 9; ++s) g[s] = bok ? dyw[boff + 4 * s] : 0.f;
+    };
+    // (rows requested after the next tile's prefetch wait for it — vmcnt retires in order — so all TY rows of this
+    //  tile are requested before it: one float4 per lane and row)
+    f32x4 raw[TY];
+#pragma unroll
+    for (int hr = 0; hr < TY; ++hr) raw[hr] = load_raw(hr);
     if (tile + 1 < t_end) { slots(tile + 1, od0, oh0, ow0); gload(); }
     const int lrow = (wid * IH) * RS + lk;               // this wave's depth slice, column 4s + lk added below
-    auto load_g = [&](float (&g)[9], int hr) {
-      const int oh = coh0 + hr;
-      const bool row_ok = bok && cod < a.D && oh < a.H;
-      const size_t rbase = ((size_t)cod * a.H + oh) * a.W;
-#pragma unroll
-      for (int s = 0; s < 9; ++s) {
-        const int ul = 4 * s + lk - bkw;                 // output column (tile-local) paired with input column 4s + lk
-        const int ow = cow0 + ul;
-        g[s] = (row_ok && ul >= 0 && ul < 32 && ow < a.W) ? dyc[rbase + ow] : 0.f;
-      }
-    };
-    float g[9], gn[9];
-    load_g(g, 0);
+    put_row(raw[0]);
 #pragma unroll
     for (int hr = 0; hr < TY; ++hr) {
-      if (hr + 1 < TY) load_g(gn, hr + 1);               // next row's dy behind this row's MFMAs
+      float g[9];
+      get_row(g);
+      if (hr + 1 < TY) put_row(raw[hr + 1]);             // a wave's LDS operations execute in order: safe after the reads
 #pragma unroll
       for (int s = 0; s < 9; ++s) {
 #pragma unroll
@@ -601,8 +618,6 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_smallco_kernel(BwSArgs a)
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, g[s], acc[t], 0, 0, 0);
         }
       }
-#pragma unroll
-      for (int s = 0; s < 9; ++s) g[s] = gn[s];
     }
   }
   // ---- cross-wave reduction, one partial per (chunk, co, ci, tap): D row q = 16t + 4*lk + r, col = (co, kw) ------------
