@@ -9,9 +9,11 @@
 // its accumulators across the 64 lanes and writes one partial per (chunk, co, ci, tap); a second kernel
 // sums the chunk partials in fixed order (deterministic, no atomics).
 #include "common.h"
+#include <algorithm>
 
 void dpi_conv_out_dims(const dpi_conv_desc* d, int* Do, int* Ho, int* Wo);
 size_t dpi_conv_bwd_weight_mfma_ws_floats(const dpi_conv_desc* d);
+bool dpi_conv_bwd_weight_mfma_swapped(const dpi_conv_desc* d, const float* chain);
 int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws,
                                  hipStream_t st);
 size_t dpi_conv_pw_bwd_weight_mfma_ws_floats(const dpi_conv_desc* d);
@@ -23,6 +25,11 @@ int dpi_conv_bwd_weight_smallco_run(const dpi_conv_desc* d, const float* x, cons
 static bool bw_use_smallco(const dpi_conv_desc* d) {
   return d->k == 3 && d->kd == 3 && d->stride == 1 && d->Cout <= 5 && (size_t)d->D * d->H * d->W >= 32768 &&
          (size_t)d->D * d->H * d->W < ((size_t)1 << 26);   // one 32-bit buffer offset spans the (<= 5) dY channels
+}
+// few output channels, input not chained: the MFMA kernel in its swapped orientation (X rows x (co, tap) columns)
+static bool bw_use_mfma_swapped(const dpi_conv_desc* d, const float* x_chain) {
+  return d->k == 3 && d->stride == 1 && d->Cin >= 8 && (size_t)d->D * d->H * d->W < ((size_t)1 << 25) &&
+         dpi_conv_bwd_weight_mfma_swapped(d, x_chain);
 }
 static int g_bw_mfma_min_cout = 8;
 extern "C" void dpi_set_bwd_weight_mfma_min_cout(int n) { g_bw_mfma_min_cout = n; }
@@ -282,10 +289,12 @@ BwPlan plan(const dpi_conv_desc* d) {
 extern "C" size_t dpi_conv_bwd_weight_ws_floats(const dpi_conv_desc* d) {
   if (!d || d->Cin <= 0 || d->Cout <= 0) return 0;
   if (bw_use_mfma(d)) return dpi_conv_bwd_weight_mfma_ws_floats(d);
-  if (bw_use_smallco(d)) return dpi_conv_bwd_weight_smallco_ws_floats(d);
+  // whether the swapped MFMA path runs depends on the chain given at launch: size for either
+  const size_t sw = bw_use_mfma_swapped(d, nullptr) ? dpi_conv_bwd_weight_mfma_ws_floats(d) : 0;
+  if (bw_use_smallco(d)) return std::max(sw, dpi_conv_bwd_weight_smallco_ws_floats(d));
   if (d->k == 1 && d->Cout >= g_bw_mfma_min_cout) return dpi_conv_pw_bwd_weight_mfma_ws_floats(d);
   const BwPlan p = plan(d);
-  return (size_t)p.nchunks * d->Cout * d->Cin * d->kd * d->k * d->k;
+  return std::max(sw, (size_t)p.nchunks * d->Cout * d->Cin * d->kd * d->k * d->k);
 }
 
 extern "C" int dpi_conv_bwd_weight(const dpi_conv_desc* d, const float* x, const float* x_chain, const float* dy,
@@ -294,7 +303,7 @@ extern "C" int dpi_conv_bwd_weight(const dpi_conv_desc* d, const float* x, const
   DPI_REQUIRE((d->k == 1 || d->k == 3) && (d->kd == d->k || d->kd == 1) && (d->stride == 1 || d->stride == 2),
               "conv_bwd_weight: unsupported k=%d kd=%d stride=%d", d->k, d->kd, d->stride);
   hipStream_t st = (hipStream_t)stream;
-  if (bw_use_mfma(d)) {
+  if (bw_use_mfma(d) || bw_use_mfma_swapped(d, x_chain)) {
     if (ws_floats < dpi_conv_bwd_weight_mfma_ws_floats(d)) {
       dpi_set_error("conv_bwd_weight: workspace %zu < %zu floats", ws_floats, dpi_conv_bwd_weight_mfma_ws_floats(d));
       return DPI_E_WORKSPACE;

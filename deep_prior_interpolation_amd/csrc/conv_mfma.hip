@@ -334,6 +334,10 @@ struct BwMArgs {
   int Cin, Cout;
   int D, H, W;
   int ntd, nth, ntw, ntiles, tiles_per_chunk;
+  // swap = 1: the roles are exchanged — `x` (staged in LDS, 4 channels per block, tap-shifted) is dY and `dy` (the
+  // 16-row A operand) is X:  D[ci][(co, t')] = sum_v X[ci][v] dY[co][v + t'] = dW[co][ci][TAPS-1-t'].  With few output
+  // channels (64 -> 4: M = 4 of 16 rows the usual way round) this fills the tile: M = 16 input channels, N = 4 co x 27.
+  int swap;
 };
 
 template <int KD, int S, int NR, int NH>
@@ -478,8 +482,10 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
     const int l = e & 63, r = (e >> 6) & 3, t = e >> 8;
     const float sum = red[e] + red[e + NTQ * 256] + red[e + 2 * NTQ * 256] + red[e + 3 * NTQ * 256];
     const int co = n0 + 4 * (l >> 4) + r, q = t * 16 + (l & 15), ci = c0 + q / TAPS, tap = q % TAPS;
-    if (co < a.Cout && q < NQ && ci < a.Cin)
-      a.ws[(((size_t)blockIdx.x * a.Cout + co) * a.Cin + ci) * TAPS + tap] = sum;
+    if (co < a.Cout && q < NQ && ci < a.Cin) {
+      if (a.swap) a.ws[(((size_t)blockIdx.x * a.Cin + ci) * a.Cout + co) * TAPS + (TAPS - 1 - tap)] = sum;   // (staged, A) = (co, ci)
+      else a.ws[(((size_t)blockIdx.x * a.Cout + co) * a.Cin + ci) * TAPS + tap] = sum;
+    }
   }
 }
 
@@ -824,15 +830,22 @@ int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain
   return dpi_check_launch("conv_mfma");
 }
 
+// tile utilisation of the two orientations (rows padded to 16, staged channels to 4)
+static bool mfma_bw_swap_better(const dpi_conv_desc* d) {
+  if (d->stride != 1) return false;
+  auto util = [](int rows, int staged) { return (double)rows / (16.0 * cdiv(rows, 16)) * staged / (4.0 * cdiv(staged, 4)); };
+  return util(d->Cin, d->Cout) > 1.15 * util(d->Cout, d->Cin);
+}
+
 struct MfmaBwPlan { int nchunks, tiles_per_chunk, ntiles, ntd, nth, ntw, nr, nh; };
-static MfmaBwPlan mfma_bw_plan(const dpi_conv_desc* d) {
+static MfmaBwPlan mfma_bw_plan(const dpi_conv_desc* d, bool swap = false) {
   MfmaBwPlan p{};
   if (d->stride == 1) { p.nr = 8; p.nh = 2; }
   else { int Do, Ho, Wo; dpi_conv_out_dims(d, &Do, &Ho, &Wo); p.nr = 2; p.nh = Wo > 16 ? 2 : 1; }
   p.ntiles = dpi_mfma_tiles(d, p.nr, p.nh, &p.ntd, &p.nth, &p.ntw);
   const size_t per = (size_t)d->Cout * d->Cin * d->kd * 9;
   const size_t max_chunks_mem = per ? ((size_t)32 << 20) / per : 1;
-  const size_t blocks_other = (size_t)cdiv(d->Cin, 4) * cdiv(d->Cout, 16);
+  const size_t blocks_other = swap ? (size_t)cdiv(d->Cout, 4) * cdiv(d->Cin, 16) : (size_t)cdiv(d->Cin, 4) * cdiv(d->Cout, 16);
   size_t want = cdivz(2048, blocks_other);
   if (want > (size_t)p.ntiles) want = p.ntiles;
   if (want > max_chunks_mem) want = max_chunks_mem;
@@ -843,15 +856,21 @@ static MfmaBwPlan mfma_bw_plan(const dpi_conv_desc* d) {
 }
 
 size_t dpi_conv_bwd_weight_mfma_ws_floats(const dpi_conv_desc* d) {
-  const MfmaBwPlan p = mfma_bw_plan(d);
-  return (size_t)p.nchunks * d->Cout * d->Cin * d->kd * 9;
+  const int n0 = mfma_bw_plan(d, false).nchunks, n1 = mfma_bw_swap_better(d) ? mfma_bw_plan(d, true).nchunks : 0;
+  return (size_t)(n0 > n1 ? n0 : n1) * d->Cout * d->Cin * d->kd * 9;     // either orientation (the chain decides at run time)
 }
+bool dpi_conv_bwd_weight_mfma_swapped(const dpi_conv_desc* d, const float* chain) { return chain == nullptr && mfma_bw_swap_better(d); }
 
 int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws,
                                  hipStream_t st) {
-  const MfmaBwPlan p = mfma_bw_plan(d);
-  BwMArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk};
+  const bool swap = dpi_conv_bwd_weight_mfma_swapped(d, chain);     // the chain can only be applied to the staged tensor
+  const MfmaBwPlan p = mfma_bw_plan(d, swap);
+  BwMArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk, 0};
   dim3 grid(p.nchunks, cdiv(d->Cin, 4), cdiv(d->Cout, 16));
+  if (swap) {
+    a.x = dy; a.chain = nullptr; a.dy = x; a.Cin = d->Cout; a.Cout = d->Cin; a.swap = 1;
+    grid = dim3(p.nchunks, cdiv(d->Cout, 4), cdiv(d->Cin, 16));
+  }
   if (d->stride == 1) {
     if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<grid, 256, 0, st>>>(a);
     else conv_bwd_weight_mfma_kernel<1, 1, 8, 2><<<grid, 256, 0, st>>>(a);
