@@ -97,10 +97,13 @@ class ResPath(nn.Module):
             self.length = 1
             self.net = nn.Sequential(c3, c1, bn, self.dr)
 
-    def forward(self, x):
-        if (FUSE_BLOCKS and self.nd == 3 and isinstance(self.act, hnn.LeakyReLU) and self.dr.p == 0.0
+    def _fusable(self):
+        return (self.nd == 3 and isinstance(self.act, hnn.LeakyReLU) and self.dr.p == 0.0
                 and all(isinstance(m._parts()[2], hnn.LeakyReLU) and m._parts()[2].negative_slope == self.act.negative_slope
-                        for m in (self.conv3x3, self.conv1x1))):
+                        for m in (self.conv3x3, self.conv1x1)))
+
+    def forward(self, x):
+        if FUSE_BLOCKS and self._fusable():
             return ops.respath3d(x, self, self.act.negative_slope)
         if self.nd == 3:
             t, b = ops.add(self.conv1x1(x), self.conv3x3(x)), self.bn
@@ -112,12 +115,32 @@ class ResPath(nn.Module):
         return self.dr(b(self.dr(self.act(t))))
 
 
+class SkipConcat(Concat):
+    """Concat(1, skip, deeper) of one U-Net level.  When the skip branch is a fusable ResPath3d and the deeper branch ends
+    in an Upsample, both write directly into the concatenated tensor (ops.SkipJoinFn); otherwise plain Concat."""
+
+    def forward(self, x):
+        skip, deeper = list(self._modules.values())
+        if FUSE_BLOCKS and isinstance(deeper, DownPath) and len(skip) == 1:
+            rp = skip[0]
+            mods = list(deeper._modules.values())
+            if isinstance(rp, ResPath) and rp._fusable() and isinstance(mods[-1], hnn.Upsample):
+                deep = deeper(x, stop_before_last=True)
+                if deep.ndim == 5:
+                    return ops.skip_join(x, deep, rp, rp.act.negative_slope, mods[-1].mode)
+                return ops.concat_crop([rp(x), mods[-1](deep)])
+        return super().forward(x)
+
+
 class DownPath(Seq):
     """The `deeper` branch: stride-2 conv [-> BN] -> act -> dropout -> block -> [inner] -> upsample.  Same children and
     names as a plain Seq; only the conv -> BN -> LeakyReLU head (3-D) is executed as one fused op."""
 
-    def forward(self, x):
+    def forward(self, x, stop_before_last=False):
         mods = list(self._modules.values())
+        return self._run(mods[:-1] if stop_before_last else mods, x)
+
+    def _run(self, mods, x):
         if (len(mods) >= 3 and isinstance(mods[1], (hnn.BatchNorm3d, hnn.BatchNorm2d)) and isinstance(mods[2], hnn.LeakyReLU)
                 and isinstance(mods[0], nn.Sequential)):
             conv_m, bn, act = mods[0][0], mods[1], mods[2]
@@ -153,7 +176,7 @@ def _mulresunet(nd, num_input_channels, num_output_channels, num_channels_down, 
         deeper.add(block)
         if num_channels_skip[i - 1] != 0:
             skip.add(ResPath(nd, depth, num_channels_skip[i - 1], act_fun, need_bias, dropout))
-            cur.add(Concat(1, skip, deeper))
+            cur.add(SkipConcat(1, skip, deeper))
         else:
             cur.add(deeper)
         inner = Seq()

@@ -466,6 +466,82 @@ class ResPath3dFn(torch.autograd.Function):
         return dx, None, None, dw3, z(b3), dg3, de3, dw1, z(b1), dg1, de1, dgB, deB
 
 
+class SkipJoinFn(torch.autograd.Function):
+    """One U-Net level join of the 3-D MultiRes-UNet as a single node (reference mulresunet.py:227-243 + Concat3D):
+         cat[:, :Cs] = ResPath3d(x)            cat[:, Cs:] = Upsample(x2)(deep), cropped to x's spatial size
+    Both producers write straight into the concat buffer (no crop-copy pass); the backward hands the two channel slices
+    of d(cat) to the ResPath backward and the up-sampling adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, deep, rp, slope, linear, *p):
+        x, deep = _req(x, "skip input"), _req(deep, "deep input")
+        (w3, b3, g3, e3, w1, b1, g1, e1, gB, eB) = p
+        L = _lib.load()
+        f32 = dict(dtype=torch.float32, device=x.device)
+        Cs = w3.shape[0]
+        Cd, Dd, Hd, Wd = _dims(deep)
+        bn3_, bn1_ = rp.conv3x3._parts()[1], rp.conv1x1._parts()[1]
+        d3, d1 = make_desc(x, w3, 1), make_desc(x, w1, 1)
+        Do, Ho, Wo = desc_out_dims(d3)
+        if not (Do <= 2 * Dd and Ho <= 2 * Hd and Wo <= 2 * Wd):
+            raise _lib.DpiError("skip_join: the up-sampled branch is smaller than the skip branch")
+        V = Do * Ho * Wo
+        r3 = torch.empty(_like_spatial(x, Cs, Do, Ho, Wo), **f32)
+        r1 = torch.empty_like(r3)
+        mi3, mi1, miB = (torch.empty(2 * Cs, **f32) for _ in range(3))
+        ch3, ch1, chB = (torch.empty(5 * Cs, **f32) for _ in range(3))
+        _cba_raw(d3, x, None, w3, b3, bn3_, slope, r3, mi3, ch3)
+        _cba_raw(d1, x, None, w1, b1, bn1_, slope, r1, mi1, ch1)
+        t = torch.empty_like(r3)
+        nblk = L.dpi_stat_blocks(Cs, V)
+        part = torch.empty(nblk * Cs * 2, dtype=torch.float64, device=x.device)
+        check(L.dpi_chain_add_stats(ptr(r1), ptr(ch1), ptr(r3), ptr(ch3), Cs, V, slope, ptr(t), ptr(part), stream()),
+              "dpi_chain_add_stats")
+        B = rp.bn
+        raw_bn_finalize(part, nblk, Cs, V, gB, eB, slope, B.running_mean, B.running_var, B.num_batches_tracked, miB, chB,
+                        act_first=1)
+        cat = torch.empty(_like_spatial(x, Cs + Cd, Do, Ho, Wo), **f32)
+        raw_chain_apply(t, chB, Cs, V, cat[:, :Cs])
+        check(L.dpi_upsample2x_fwd(ptr(deep), None, Cd, Dd, Hd, Wd, Do, Ho, Wo, int(linear), ptr(cat[:, Cs:]), stream()),
+              "dpi_upsample2x_fwd")
+        ctx.save_for_backward(x, r3, r1, t, mi3, mi1, miB, *[q for q in p if q is not None])
+        ctx.none_mask = [q is None for q in p]
+        ctx.descs = (d3, d1)
+        ctx.slope = float(slope)
+        ctx.up = (Cs, Cd, Dd, Hd, Wd, Do, Ho, Wo, int(linear), deep.shape)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        dcat = _req(dcat, "skip-join grad")
+        x, r3, r1, t, mi3, mi1, miB = ctx.saved_tensors[:7]
+        it = iter(ctx.saved_tensors[7:])
+        (w3, b3, g3, e3, w1, b1, g1, e1, gB, eB) = [None if isnone else next(it) for isnone in ctx.none_mask]
+        d3, d1 = ctx.descs
+        slope = ctx.slope
+        Cs, Cd, Dd, Hd, Wd, Do, Ho, Wo, linear, deep_shape = ctx.up
+        L = _lib.load()
+        ddeep = None
+        if ctx.needs_input_grad[1]:
+            ddeep = torch.empty(deep_shape, dtype=torch.float32, device=dcat.device)
+            check(L.dpi_upsample2x_bwd(ptr(dcat[:, Cs:]), Cd, Dd, Hd, Wd, Do, Ho, Wo, linear, ptr(ddeep), stream()),
+                  "dpi_upsample2x_bwd")
+        dt, dgB, deB = _bn_backward(dcat[:, :Cs], t, miB, gB, eB, slope, 1.0)
+        dr3, dg3, de3 = _bn_backward(dt, r3, mi3, g3, e3, 1.0, slope)
+        dr1, dg1, de1 = _bn_backward(dt, r1, mi1, g1, e1, 1.0, slope)
+        del dt
+        dw3, dw1 = torch.empty_like(w3), torch.empty_like(w1)
+        raw_conv_bwd_weight(d3, x, None, dr3, dw3)
+        raw_conv_bwd_weight(d1, x, None, dr1, dw1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            raw_conv_bwd_data(d1, dr1, w1, dx)
+            raw_conv_bwd_data(d3, dr3, w3, dx, accumulate=True)
+        z = _zeros_like_or_none
+        return dx, ddeep, None, None, None, dw3, z(b3), dg3, de3, dw1, z(b1), dg1, de1, dgB, deB
+
+
 class LeakyReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, slope):
@@ -688,6 +764,12 @@ def block3d(x, blk, slope):
 def respath3d(x, rp, slope):
     p = _cba_params(rp.conv3x3) + _cba_params(rp.conv1x1) + [rp.bn.weight, rp.bn.bias]
     return ResPath3dFn.apply(x, rp, slope, *p)
+
+
+def skip_join(x, deep, rp, slope, mode):
+    """cat[ResPath3d(x), Upsample(deep)] written in place (zero-copy concat)."""
+    p = _cba_params(rp.conv3x3) + _cba_params(rp.conv1x1) + [rp.bn.weight, rp.bn.bias]
+    return SkipJoinFn.apply(x, deep, rp, slope, mode != "nearest", *p)
 
 
 def leaky_relu(x, slope=0.2):
