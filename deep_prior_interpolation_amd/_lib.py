@@ -49,6 +49,8 @@ SIGNATURES = {
     "dpi_chain_apply": (_I, [_P, _P, _I, _Z, _P, _P]),
     "dpi_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _I, _Z, _P, _P]),
     "dpi_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _P, _I, _I, _Z, _P, _P, _P, _P]),
+    "dpi_bn_bwd_apply_fork": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _P, _I, _I, _Z, _P, _P, _P,
+                                   _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
     "dpi_chain_add_stats": (_I, [_P, _P, _P, _P, _I, _Z, _F, _P, _P, _P]),
     "dpi_lrelu_bwd": (_I, [_P, _P, _F, _Z, _P, _P]),
     "dpi_add": (_I, [_P, _P, _Z, _P, _P]),

@@ -281,6 +281,97 @@ __global__ __launch_bounds__(256) void chain_add_stats_kernel(const float* __res
   }
 }
 
+// ---- BN backward phase 2 fused with phase 1 of the BatchNorms the result feeds ------------------------------------------
+// dx of this BatchNorm is the incoming gradient of up to two other BatchNorm backward passes (the residual join of
+// Block3d / ResPath3d: d t -> shortcut-BN and bn1 / the two conv-BNs).  Their {sum g, sum g*xhat} partials are taken
+// while dx is still in registers, which removes their separate reduction passes (2 reads each).
+struct BnFork {
+  const float* x;            // that BatchNorm's input (raw), NULL = unused
+  const float* mean_invstd;
+  const float* gamma;
+  const float* beta;
+  const float* in_chain;
+  float post;
+  double* partials;          // [nblk][C][2]
+};
+__global__ __launch_bounds__(256) void bn_bwd_apply_fork_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ in_chain,
+                                                                float pre, float post, const double* __restrict__ partials, int nblk_in,
+                                                                int C, size_t V, int nblk, float* __restrict__ dx,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, BnFork fa, BnFork fb) {
+  const int c = blockIdx.y, b = blockIdx.x;
+  __shared__ double tot[2];
+  if (threadIdx.x < 64) {
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nblk_in; i += 64) {
+      s += partials[((size_t)i * C + c) * 2 + 0];
+      q += partials[((size_t)i * C + c) * 2 + 1];
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (threadIdx.x == 0) { tot[0] = s; tot[1] = q; }
+  }
+  __syncthreads();
+  const BnBwd k = bn_bwd_consts(mean_invstd, gamma, beta, in_chain, pre, post, C, c);
+  const float k1 = (float)(tot[0] / (double)V), k2 = (float)(tot[1] / (double)V);
+  if (b == 0 && threadIdx.x == 0) {
+    if (dgamma) dgamma[c] = (float)tot[1];
+    if (dbeta) dbeta[c] = (float)tot[0];
+  }
+  const BnBwd ka = fa.x ? bn_bwd_consts(fa.mean_invstd, fa.gamma, fa.beta, fa.in_chain, 1.f, fa.post, C, c) : k;
+  const BnBwd kb = fb.x ? bn_bwd_consts(fb.mean_invstd, fb.gamma, fb.beta, fb.in_chain, 1.f, fb.post, C, c) : k;
+  const size_t span = stat_span(V, nblk);
+  const size_t beg = (size_t)b * span, end = beg + span < V ? beg + span : V;
+  const float* __restrict__ xc = x + (size_t)c * V;
+  const float* __restrict__ gc = dy + (size_t)c * V;
+  const float* __restrict__ xa = fa.x ? fa.x + (size_t)c * V : xc;
+  const float* __restrict__ xb = fb.x ? fb.x + (size_t)c * V : xc;
+  float* __restrict__ oc = dx + (size_t)c * V;
+  double sa = 0.0, qa = 0.0, sb = 0.0, qb = 0.0;
+  const bool vec = (V & 3) == 0;
+  for (size_t i = beg + (size_t)threadIdx.x * 4; i < end; i += 1024) {
+    float xv[4], gv[4], av[4], bv[4], o[4];
+    if (vec) {
+      const float4 f = *reinterpret_cast<const float4*>(xc + i);
+      const float4 g = *reinterpret_cast<const float4*>(gc + i);
+      xv[0] = f.x; xv[1] = f.y; xv[2] = f.z; xv[3] = f.w;
+      gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
+      if (fa.x) { const float4 t = *reinterpret_cast<const float4*>(xa + i); av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w; }
+      if (fb.x) { const float4 t = *reinterpret_cast<const float4*>(xb + i); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool in = i + j < end;
+        xv[j] = in ? xc[i + j] : 0.f; gv[j] = in ? gc[i + j] : 0.f;
+        av[j] = (in && fa.x) ? xa[i + j] : 0.f; bv[j] = (in && fb.x) ? xb[i + j] : 0.f;
+      }
+    }
+    float lsa = 0.f, lqa = 0.f, lsb = 0.f, lqb = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float xh, g;
+      bn_bwd_elem(k, xv[j], gv[j], xh, g);
+      const float du = k.a * (g - k1 - xh * k2);
+      o[j] = (k.pre == 1.f || xv[j] > 0.f) ? du : du * k.pre;
+      if (i + j < end) {
+        if (fa.x) { float h, ga_; bn_bwd_elem(ka, av[j], o[j], h, ga_); lsa += ga_; lqa = fmaf(ga_, h, lqa); }
+        if (fb.x) { float h, gb_; bn_bwd_elem(kb, bv[j], o[j], h, gb_); lsb += gb_; lqb = fmaf(gb_, h, lqb); }
+      }
+    }
+    if (vec) *reinterpret_cast<float4*>(oc + i) = make_float4(o[0], o[1], o[2], o[3]);
+    else
+      for (int j = 0; j < 4 && i + j < end; ++j) oc[i + j] = o[j];
+    sa += lsa; qa += lqa; sb += lsb; qb += lqb;
+  }
+  __shared__ double sh[16];
+  const double SA = block_sum(sa, sh), QA = block_sum(qa, sh + 4), SB = block_sum(sb, sh + 8), QB = block_sum(qb, sh + 12);
+  if (threadIdx.x == 0) {
+    if (fa.x) { fa.partials[((size_t)b * C + c) * 2 + 0] = SA; fa.partials[((size_t)b * C + c) * 2 + 1] = QA; }
+    if (fb.x) { fb.partials[((size_t)b * C + c) * 2 + 0] = SB; fb.partials[((size_t)b * C + c) * 2 + 1] = QB; }
+  }
+}
+
 __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float slope,
                                                         size_t n, float* __restrict__ dx) {
   const bool vec = (n & 3) == 0;
@@ -603,6 +694,22 @@ extern "C" int dpi_bn_bwd_apply(const float* dy, const float* x, const float* me
                                                                                       post_slope, partials, nblk, C, V, dx, dgamma,
                                                                                       dbeta);
   return dpi_check_launch("bn_bwd_apply");
+}
+
+extern "C" int dpi_bn_bwd_apply_fork(const float* dy, const float* x, const float* mean_invstd, const float* gamma, const float* beta,
+                                     const float* in_chain, float pre_slope, float post_slope, const double* partials, int nblk, int C,
+                                     size_t V, float* dx, float* dgamma, float* dbeta, const float* xa, const float* mi_a,
+                                     const float* gamma_a, const float* beta_a, const float* chain_a, float post_a, double* partials_a,
+                                     const float* xb, const float* mi_b, const float* gamma_b, const float* beta_b, const float* chain_b,
+                                     float post_b, double* partials_b, void* stream) {
+  DPI_REQUIRE(dy && x && mean_invstd && partials && dx && C > 0 && V > 0 && nblk > 0, "bn_bwd_apply_fork: bad argument");
+  DPI_REQUIRE(!in_chain || pre_slope == 1.f, "bn_bwd_apply_fork: in_chain excludes pre_slope");
+  DPI_REQUIRE((!xa || (mi_a && partials_a)) && (!xb || (mi_b && partials_b)), "bn_bwd_apply_fork: incomplete follow-up BatchNorm");
+  const int nb = dpi_stat_blocks(C, V);
+  const BnFork fa{xa, mi_a, gamma_a, beta_a, chain_a, post_a, partials_a}, fb{xb, mi_b, gamma_b, beta_b, chain_b, post_b, partials_b};
+  bn_bwd_apply_fork_kernel<<<dim3(nb, C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, beta, in_chain, pre_slope, post_slope,
+                                                                        partials, nblk, C, V, nb, dx, dgamma, dbeta, fa, fb);
+  return dpi_check_launch("bn_bwd_apply_fork");
 }
 
 extern "C" int dpi_chain_add_stats(const float* a, const float* chain_a, const float* b, const float* chain_b, int C, size_t V,

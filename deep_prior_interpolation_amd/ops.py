@@ -211,6 +211,46 @@ def _bn_backward(dy, x, mi, gamma, beta, pre_slope, post_slope, in_chain=None, d
     return dx, dgamma, dbeta
 
 
+def _bn_backward_fork(dy, x, mi, gamma, beta, pre_slope, post_slope, forks):
+    """BatchNorm backward of (dy, x) whose result dx is the incoming gradient of the BatchNorms in `forks`
+    (list of up to two (x_k, mi_k, gamma_k, beta_k, in_chain_k, post_slope_k)).  Returns dx, dgamma, dbeta and, per fork,
+    its already-reduced phase-1 partials (nblk, tensor) so that `_bn_backward_apply` can finish it without a reduce pass."""
+    L = _lib.load()
+    C_ = x.shape[1]
+    V = x.numel() // C_
+    nblk = L.dpi_stat_blocks(C_, V)
+    part = torch.empty(nblk * C_ * 2, dtype=torch.float64, device=x.device)
+    check(L.dpi_bn_bwd_reduce(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), None, pre_slope, post_slope, C_, V, ptr(part),
+                              stream()), "dpi_bn_bwd_reduce")
+    dx = torch.empty_like(x)
+    dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+    fparts = [torch.empty(nblk * C_ * 2, dtype=torch.float64, device=x.device) for _ in forks]
+    fa = []
+    for k in range(2):
+        if k < len(forks):
+            xk, mik, gk, ek, chk, postk = forks[k]
+            fa += [ptr(xk), ptr(mik), ptr(gk), ptr(ek), ptr(chk), postk, ptr(fparts[k])]
+        else:
+            fa += [None, None, None, None, None, 1.0, None]
+    check(L.dpi_bn_bwd_apply_fork(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), None, pre_slope, post_slope, ptr(part), nblk, C_, V,
+                                  ptr(dx), ptr(dgamma), ptr(dbeta), *fa, stream()), "dpi_bn_bwd_apply_fork")
+    return dx, dgamma, dbeta, [(nblk, fp) for fp in fparts]
+
+
+def _bn_backward_apply(dy, x, mi, gamma, beta, pre_slope, post_slope, red, in_chain=None, dx=None):
+    """phase 2 only, from partials `red` = (nblk, tensor) produced by _bn_backward_fork."""
+    L = _lib.load()
+    C_ = x.shape[1]
+    V = x.numel() // C_
+    nblk, part = red
+    if dx is None:
+        dx = torch.empty_like(x)
+    dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+    check(L.dpi_bn_bwd_apply(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), ptr(in_chain), pre_slope, post_slope, ptr(part), nblk,
+                             C_, V, ptr(dx), ptr(dgamma), ptr(dbeta), stream()), "dpi_bn_bwd_apply")
+    return dx, dgamma, dbeta
+
+
 def _pre_chain(C_, pre_slope, device):
     return None if pre_slope == 1.0 else slope_chain(C_, pre_slope, device)
 
@@ -377,9 +417,10 @@ class Block3dFn(torch.autograd.Function):
         c1, c2, c3 = ctx.split
         s1, s2, s3 = slice(0, c1), slice(c1, c1 + c2), slice(c1 + c2, c1 + c2 + c3)
         ch1, ch2 = CH[:c1 * 5], CH[c1 * 5:(c1 + c2) * 5]
-        dt, dgB, deB = _bn_backward(dy, t, miB, gB, eB, slope, 1.0)
-        dS, dgs, des = _bn_backward(dt, S, miS, gs, es, 1.0, slope)
-        dcat, dgA, deA = _bn_backward(dt, R, miA, gA, eA, 1.0, 1.0, in_chain=CH)
+        dt, dgB, deB, (redS, redA) = _bn_backward_fork(dy, t, miB, gB, eB, slope, 1.0,
+                                                       [(S, miS, gs, es, None, slope), (R, miA, gA, eA, CH, 1.0)])
+        dS, dgs, des = _bn_backward_apply(dt, S, miS, gs, es, 1.0, slope, redS)
+        dcat, dgA, deA = _bn_backward_apply(dt, R, miA, gA, eA, 1.0, 1.0, redA, in_chain=CH)
         del dt
         dR = torch.empty_like(R)
         # o3 -> o2 -> o1: each conv's backward-data ACCUMULATES into the concat gradient of its input slice
@@ -450,9 +491,10 @@ class ResPath3dFn(torch.autograd.Function):
         (w3, b3, g3, e3, w1, b1, g1, e1, gB, eB) = [None if isnone else next(it) for isnone in ctx.none_mask]
         d3, d1 = ctx.descs
         slope = ctx.slope
-        dt, dgB, deB = _bn_backward(dy, t, miB, gB, eB, slope, 1.0)
-        dr3, dg3, de3 = _bn_backward(dt, r3, mi3, g3, e3, 1.0, slope)
-        dr1, dg1, de1 = _bn_backward(dt, r1, mi1, g1, e1, 1.0, slope)
+        dt, dgB, deB, (red3, red1) = _bn_backward_fork(dy, t, miB, gB, eB, slope, 1.0,
+                                                       [(r3, mi3, g3, e3, None, slope), (r1, mi1, g1, e1, None, slope)])
+        dr3, dg3, de3 = _bn_backward_apply(dt, r3, mi3, g3, e3, 1.0, slope, red3)
+        dr1, dg1, de1 = _bn_backward_apply(dt, r1, mi1, g1, e1, 1.0, slope, red1)
         del dt
         dw3, dw1 = torch.empty_like(w3), torch.empty_like(w1)
         raw_conv_bwd_weight(d3, x, None, dr3, dw3)
@@ -526,9 +568,10 @@ class SkipJoinFn(torch.autograd.Function):
             ddeep = torch.empty(deep_shape, dtype=torch.float32, device=dcat.device)
             check(L.dpi_upsample2x_bwd(ptr(dcat[:, Cs:]), Cd, Dd, Hd, Wd, Do, Ho, Wo, linear, ptr(ddeep), stream()),
                   "dpi_upsample2x_bwd")
-        dt, dgB, deB = _bn_backward(dcat[:, :Cs], t, miB, gB, eB, slope, 1.0)
-        dr3, dg3, de3 = _bn_backward(dt, r3, mi3, g3, e3, 1.0, slope)
-        dr1, dg1, de1 = _bn_backward(dt, r1, mi1, g1, e1, 1.0, slope)
+        dt, dgB, deB, (red3, red1) = _bn_backward_fork(dcat[:, :Cs], t, miB, gB, eB, slope, 1.0,
+                                                       [(r3, mi3, g3, e3, None, slope), (r1, mi1, g1, e1, None, slope)])
+        dr3, dg3, de3 = _bn_backward_apply(dt, r3, mi3, g3, e3, 1.0, slope, red3)
+        dr1, dg1, de1 = _bn_backward_apply(dt, r1, mi1, g1, e1, 1.0, slope, red1)
         del dt
         dw3, dw1 = torch.empty_like(w3), torch.empty_like(w1)
         raw_conv_bwd_weight(d3, x, None, dr3, dw3)

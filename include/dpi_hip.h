@@ -114,6 +114,16 @@ int dpi_bn_bwd_apply(const float* dy, const float* x, const float* mean_invstd, 
                      const float* beta, const float* in_chain, float pre_slope, float post_slope,
                      const double* partials, int nblk, int C, size_t V, float* dx, float* dgamma,
                      float* dbeta, void* stream);
+/* dpi_bn_bwd_apply fused with phase 1 (dpi_bn_bwd_reduce) of up to two BatchNorms whose incoming gradient is this dx
+ * (the residual joins of Block3d / ResPath3d, mulresunet.py:92-94,109-111): partials_a/b[dpi_stat_blocks][C][2] receive
+ * {sum g, sum g*xhat} of dx against (xa, mi_a, gamma_a, beta_a, chain_a, post_a) resp. (xb, ...); xa / xb may be NULL. */
+int dpi_bn_bwd_apply_fork(const float* dy, const float* x, const float* mean_invstd, const float* gamma,
+                          const float* beta, const float* in_chain, float pre_slope, float post_slope,
+                          const double* partials, int nblk, int C, size_t V, float* dx, float* dgamma,
+                          float* dbeta, const float* xa, const float* mi_a, const float* gamma_a,
+                          const float* beta_a, const float* chain_a, float post_a, double* partials_a,
+                          const float* xb, const float* mi_b, const float* gamma_b, const float* beta_b,
+                          const float* chain_b, float post_b, double* partials_b, void* stream);
 /* t = T_a(a) + T_b(b);  partials[nblk][C][2] = {sum, sum^2} of act(t) with LeakyReLU(slope): the residual join
  * followed by act -> BatchNorm of Block3d / ResPath3d (mulresunet.py:92-94,109-111) in one pass. */
 int dpi_chain_add_stats(const float* a, const float* chain_a, const float* b, const float* chain_b, int C,
