@@ -43,6 +43,7 @@ SIGNATURES = {
     "dpi_conv_bwd_weight": (_I, [_DESC, _P, _P, _P, _P, _P, _Z, _P]),
     "dpi_set_mfma_min_cout": (None, [_I]),
     "dpi_set_bwd_weight_mfma_min_cout": (None, [_I]),
+    "dpi_set_fewco_mfma": (None, [_I]),
     "dpi_stat_blocks": (_I, [_I, _Z]),
     "dpi_channel_stats": (_I, [_P, _P, _I, _Z, _P, _P]),
     "dpi_bn_finalize": (_I, [_P, _I, _I, _Z, _P, _P, _F, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P]),

@@ -437,6 +437,12 @@ int check_desc(const dpi_conv_desc* d) {
 int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
                       double* partials, bool flip, int accumulate, hipStream_t st);
 void dpi_conv_pw_mfma_plan(size_t V, int cout, int* vox_per_block, int* mt);
+bool dpi_conv_fewco_usable(const dpi_conv_desc* d);
+int dpi_conv_fewco_tiles(const dpi_conv_desc* d, int* ntd, int* nth, int* ntw);
+int dpi_conv_fewco_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
+                            double* partials, hipStream_t st);
+static int g_fewco_mfma = 1;
+extern "C" void dpi_set_fewco_mfma(int on) { g_fewco_mfma = on; }
 int dpi_conv_pw_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
                          double* partials, bool flip, int accumulate, hipStream_t st);
 int dpi_conv_bwd_data_s2_mfma_run(const dpi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, hipStream_t st);
@@ -467,6 +473,7 @@ extern "C" int dpi_conv_fwd_stat_blocks(const dpi_conv_desc* d) {
     dpi_mfma_variant(d, d->Cout, &nr, &nh);
     return dpi_mfma_tiles(d, nr, nh, &a, &b, &c);
   }
+  if (g_fewco_mfma && dpi_conv_fewco_usable(d)) { int a, b, c; return dpi_conv_fewco_tiles(d, &a, &b, &c); }
   const Geo g = conv_geo(d->kd, d->stride);
   return cdiv(Do, g.tz) * cdiv(Ho, g.ty) * cdiv(Wo, g.txow);
 }
@@ -483,6 +490,7 @@ static int conv_run(const dpi_conv_desc* d, const float* x, const float* chain, 
   if (d->k == 3 && cout >= g_mfma_min_cout && (d->stride == 1 || !flip))
     return dpi_conv_mfma_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
   if (d->k == 1 && cout >= g_mfma_min_cout) return dpi_conv_pw_mfma_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
+  if (!flip && !accumulate && g_fewco_mfma && dpi_conv_fewco_usable(d)) return dpi_conv_fewco_mfma_run(d, x, chain, w, bias, y, partials, st);
   const int co_b = pick_co_b(cout);
   if (d->k == 1) {
     PwArgs a{x, chain, w, bias, y, partials, cin, cout, (size_t)Do * Ho * Wo, w_out, w_in, accumulate};

@@ -78,6 +78,9 @@ int dpi_conv_bwd_weight(const dpi_conv_desc* d, const float* x, const float* x_c
  * fp32-MFMA stencil kernels (conv_mfma.hip), fewer use the VALU kernels.  Default 8. */
 void dpi_set_mfma_min_cout(int n);
 void dpi_set_bwd_weight_mfma_min_cout(int n);
+/* Tuning / test hook: 0 routes forward 3x3x3 convs with Cout <= 4 back to the VALU kernel instead of the (co, kw)-row
+ * MFMA kernel (csrc/conv_fewco_mfma.hip). */
+void dpi_set_fewco_mfma(int on);
 
 /* ---------------------------------------------------------------- BatchNorm / activations -------
  * Replaces nn.BatchNorm3d/2d in training mode (base.py:164,214; mulresunet.py:80-81,104,225) and

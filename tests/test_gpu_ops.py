@@ -66,6 +66,8 @@ CONV_RANDOM = [
     (16, 16, (3, 5, 17), 3, 1), (9, 33, (12, 16, 64), 3, 1), (212, 212, (2, 2, 2), 3, 2),
     # few-output-channel backward-weight MFMA kernel (Cout <= 5, >= 32768 voxels), channel / size tails
     (13, 4, (32, 32, 40), 3, 1), (7, 1, (33, 31, 37), 3, 1), (6, 5, (32, 32, 32), 3, 1), (64, 4, (16, 48, 64), 3, 1),
+    # few-output-channel FORWARD MFMA kernel ((co, kw) rows, 46-column tiles): Cout 1..4, ragged W / H / D tile edges
+    (25, 1, (33, 31, 50), 3, 1), (9, 3, (32, 33, 47), 3, 1), (12, 2, (34, 17, 93), 3, 1), (67, 4, (30, 24, 46), 3, 1),
 ]
 
 
@@ -108,12 +110,13 @@ def test_conv2d_vs_oracle(ops, cin, cout, shape, k, stride):
     assert rel(xg.grad, xr.grad) < 2e-6 and rel(wg.grad, wr.grad) < 5e-6 and rel(bg.grad, br.grad) < 5e-6
 
 
-def test_conv_fused_chain_and_stats(ops):
-    """conv(T(x)) with the BN-apply+LeakyReLU chain fused into the load, and the {sum, sum^2} epilogue."""
+@pytest.mark.parametrize("cin,cout,shape", [(13, 9, (7, 12, 37)), (20, 4, (32, 33, 47)), (25, 16, (12, 16, 40)), (9, 3, (40, 30, 50))])
+def test_conv_fused_chain_and_stats(ops, cin, cout, shape):
+    """conv(T(x)) with the BN-apply+LeakyReLU chain fused into the load, and the {sum, sum^2} epilogue
+    (MFMA, few-output-channel MFMA and VALU kernels)."""
     import ctypes as C
     from deep_prior_interpolation_amd import _lib
     gen = torch.Generator().manual_seed(3)
-    cin, cout, shape = 13, 9, (7, 12, 37)
     x = torch.randn((1, cin) + shape, generator=gen)
     chain = torch.stack([torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen), torch.full((cin,), 0.2),
                          torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen)], dim=1).contiguous()
@@ -132,7 +135,7 @@ def test_conv_fused_chain_and_stats(ops):
     assert rel(y, yr) < 2e-6
     p = part.view(nblk, cout, 2).sum(0).cpu()
     yr64 = yr.double()
-    np.testing.assert_allclose(p[:, 0].numpy(), yr64.sum((0, 2, 3, 4)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(p[:, 0].numpy(), yr64.sum((0, 2, 3, 4)).numpy(), rtol=1e-5, atol=2e-2)
     np.testing.assert_allclose(p[:, 1].numpy(), (yr64 ** 2).sum((0, 2, 3, 4)).numpy(), rtol=1e-5)
     # backward-weight with the same chain on x
     dy = torch.randn(yr.shape, generator=gen)
@@ -347,3 +350,22 @@ def test_data_forgetting_and_filters_in_build_input():
     T.optimize(verbose=False)
     assert len(T.history.loss) == 4 and len(T.input_list) == 3 and T.input_list[0].shape == (6, 16, 8, 8)
     assert np.isfinite(T.history.loss).all()
+
+
+@pytest.mark.parametrize("cin,cout,shape,k,stride", [(4, 64, (8, 16, 40), 3, 1), (16, 25, (8, 16, 32), 3, 1), (8, 4, (8, 8, 32), 3, 1),
+                                                     (25, 64, (8, 16, 32), 1, 1), (25, 25, (16, 16, 32), 3, 2), (13, 8, (5, 9, 33), 3, 1)])
+def test_conv_bwd_data_accumulate(ops, cin, cout, shape, k, stride):
+    """gradient fan-in: dpi_conv_bwd_data(accumulate=1) adds to the destination (every kernel family).
+    Note the roles: d describes the FORWARD conv cin -> cout; backward-data maps dy (cout) to dx (cin)."""
+    gen = torch.Generator().manual_seed(cin + 31 * cout)
+    x = torch.randn((1, cin) + shape, generator=gen).to(DEV)
+    w = (torch.randn((cout, cin, k, k, k), generator=gen) * 0.1).to(DEV)
+    d = ops.make_desc(x, w, stride)
+    Do, Ho, Wo = ops.desc_out_dims(d)
+    dy = torch.randn((1, cout, Do, Ho, Wo), generator=gen).to(DEV)
+    base = torch.randn(x.shape, generator=gen).to(DEV)
+    plain = torch.empty_like(x)
+    ops.raw_conv_bwd_data(d, dy, w, plain)
+    acc = base.clone()
+    ops.raw_conv_bwd_data(d, dy, w, acc, accumulate=True)
+    assert rel(acc, base + plain) < 1e-6
