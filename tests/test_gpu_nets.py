@@ -266,3 +266,44 @@ def test_cli_end_to_end_single_and_multi_rank_driver_agree(tmp_path, monkeypatch
     rec_dev = np.load("results/multi/reconstructed.npy")
     assert rec_dev.shape == rec_files.shape and np.isfinite(rec_dev).all()
     np.testing.assert_allclose(rec_dev, rec_files, rtol=1e-5, atol=1e-5 * np.abs(rec_files).max())
+
+
+@pytest.mark.parametrize("shape,upsample", [((16, 24, 40), "linear"), ((13, 18, 21), "nearest")])
+def test_fused_block_nodes_match_leaf_by_leaf_execution(shape, upsample):
+    """The fused autograd nodes (Block3dFn / ResPath3dFn / SkipJoinFn: zero-copy concat, chain-on-load, in-kernel gradient
+    fan-in, forked BatchNorm-backward partials) against the same module tree executed leaf by leaf: same output, loss,
+    parameter gradients and BatchNorm running statistics up to fp32 rounding."""
+    import copy
+    from deep_prior_interpolation_amd import ops
+    from deep_prior_interpolation_amd.architectures import mulresunet as M
+    torch.manual_seed(11)
+    net = M.MulResUnet3D(num_input_channels=9, num_output_channels=1, num_channels_down=[6, 12, 24], num_channels_up=[6, 12, 24],
+                         num_channels_skip=[4, 8], upsample_mode=upsample, act_fun="LeakyReLU").to(DEV)
+    net2 = copy.deepcopy(net)
+    gen = torch.Generator().manual_seed(5)
+    z = torch.randn((1, 9) + shape, generator=gen).to(DEV)
+    img = torch.randn((1, 1) + shape, generator=gen).to(DEV)
+    mask = (torch.rand((1, 1) + shape, generator=gen) > 0.4).float().to(DEV)
+    res = []
+    for fused, n in ((True, net), (False, net2)):
+        M.FUSE_BLOCKS = fused
+        try:
+            out = n(z)
+            loss, _ = ops.masked_loss(out, img, mask, "mse")
+            loss.backward()
+        finally:
+            M.FUSE_BLOCKS = True
+        res.append((out.detach(), float(loss.detach()), {k: p.grad.detach() for k, p in n.named_parameters()},
+                    {k: b.detach().clone() for k, b in n.named_buffers()}))
+    (o1, l1, g1, b1), (o2, l2, g2, b2) = res
+    assert rel(o1, o2.cpu().numpy()) < 2e-5
+    assert abs(l1 - l2) < 2e-5 * abs(l2)
+    worst = max(rel(g1[k], g2[k].cpu().numpy()) for k in g1 if float(g2[k].abs().max()) > 1e-6)
+    assert worst < 2e-3, worst        # the net is ill-conditioned (70 train-mode BNs): rounding differences are amplified
+    med = float(np.median([rel(g1[k], g2[k].cpu().numpy()) for k in g1 if float(g2[k].abs().max()) > 1e-6]))
+    assert med < 1e-4, med
+    for k in b1:
+        if "num_batches" in k:
+            assert int(b1[k]) == int(b2[k])
+        else:
+            assert rel(b1[k], b2[k].cpu().numpy()) < 1e-5
