@@ -309,7 +309,7 @@ class ConvBnActFn(torch.autograd.Function):
         y = torch.empty_like(r)
         raw_chain_apply(r, chain, d.Cout, V, y)
         ctx.save_for_backward(x, w, r, gamma, beta, mi)
-        ctx.d, ctx.slope, ctx.has_bias = d, float(slope), b is not None
+        ctx.d, ctx.slope, ctx.has_bias, ctx.bias_ref = d, float(slope), b is not None, b
         return y
 
     @staticmethod
@@ -325,7 +325,7 @@ class ConvBnActFn(torch.autograd.Function):
             dw = torch.empty_like(w)
             raw_conv_bwd_weight(d, x, None, dr, dw)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.zeros(d.Cout, dtype=torch.float32, device=x.device)
+            db = _zeros_like_or_none(ctx.bias_ref)
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None
 
 
@@ -340,8 +340,20 @@ def _cba_raw(d, x, in_chain, w, b, bn, slope, r_out, mi_out, chain_out):
                     bn.num_batches_tracked, mi_out, chain_out)
 
 
+_zero_grads = {}
+
+
 def _zeros_like_or_none(b):
-    return None if b is None else torch.zeros_like(b)
+    """Gradient of a conv bias that feeds a BatchNorm: identically zero.  One read-only zero tensor per bias is kept and
+    handed out every iteration (no fill launch); optimisers only read .grad."""
+    if b is None:
+        return None
+    key = (b.data_ptr(), tuple(b.shape), str(b.device))
+    z = _zero_grads.get(key)
+    if z is None:
+        z = torch.zeros_like(b)
+        _zero_grads[key] = z
+    return z
 
 
 class Block3dFn(torch.autograd.Function):
