@@ -846,7 +846,8 @@ static MfmaBwPlan mfma_bw_plan(const dpi_conv_desc* d, bool swap = false) {
   const size_t per = (size_t)d->Cout * d->Cin * d->kd * 9;
   const size_t max_chunks_mem = per ? ((size_t)32 << 20) / per : 1;
   const size_t blocks_other = swap ? (size_t)cdiv(d->Cout, 4) * cdiv(d->Cin, 16) : (size_t)cdiv(d->Cin, 4) * cdiv(d->Cout, 16);
-  size_t want = cdivz(2048, blocks_other);
+  size_t want = 2304 / blocks_other;   // 3 workgroups per CU x 256 CUs x 3 full rounds (a 4th, partly filled round costs ~10 %)
+  if (want < 1) want = 1;
   if (want > (size_t)p.ntiles) want = p.ntiles;
   if (want > max_chunks_mem) want = max_chunks_mem;
   if (want < 1) want = 1;

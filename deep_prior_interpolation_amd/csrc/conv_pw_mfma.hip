@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void conv_pw_mfma_kernel(PwMArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ssum[m][r] = 0.0; qsum[m][r] = 0.0; }
 
+  const int mt_valid = min(MT, (a.Cout - n0 + 15) / 16);
   for (int grp = wid; grp < a.gpb; grp += 4) {
     const size_t g0 = ((size_t)blockIdx.x * a.gpb + grp) * 64;
     const size_t v0 = g0 + 4 * lj;
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void conv_pw_mfma_kernel(PwMArgs a) {
           }
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
+            if (m >= mt_valid) continue;               // 16-channel tile entirely past Cout (block-uniform)
             float wv;
             if constexpr (WLDS) wv = wl[(ch * MT + m) * 64 + lane];
             else {
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_weight_mfma_kernel(PwBwArgs a
   for (int m = 0; m < MT; ++m) dyr[m] = a.dy + (size_t)min(co0 + m * 16 + lj, a.Cout - 1) * a.V;
 #pragma unroll
   for (int n = 0; n < NT; ++n) xr[n] = a.x + (size_t)min(ci0 + n * 16 + lj, a.Cin - 1) * a.V;
+  const int mt_valid = min(MT, (a.Cout - co0 + 15) / 16), nt_valid = min(NT, (a.Cin - ci0 + 15) / 16);
   for (size_t g0 = vbeg + (size_t)wid * 64; g0 < vend; g0 += 256) {
     const size_t v0 = g0 + 16 * lk;
     float ga[MT][16], xb[NT][16];
@@ -214,22 +217,32 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_weight_mfma_kernel(PwBwArgs a
         for (int e = 0; e < 16; ++e) { const float v = p[v0 + e < vend ? v0 + e : vbeg]; o[e] = v0 + e < vend ? v : 0.f; }
       }
     };
+    // 16-channel tiles that lie entirely past Cout / Cin (e.g. Cin = 67: the second 64-channel block holds 3 channels)
+    // are skipped — block-uniform tests; without them those tiles re-read the clamped last channel 16 times over
 #pragma unroll
-    for (int m = 0; m < MT; ++m) load16(dyr[m], ga[m]);
+    for (int m = 0; m < MT; ++m)
+      if (m < mt_valid) load16(dyr[m], ga[m]);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) load16(xr[n], xb[n]);
+    for (int n = 0; n < NT; ++n)
+      if (n < nt_valid) load16(xr[n], xb[n]);
     if (a.chain) {
 #pragma unroll
       for (int n = 0; n < NT; ++n)
+        if (n < nt_valid) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) xb[n][e] = (v0 + e < vend) ? apply_chain(ch[n], xb[n][e]) : 0.f;
+          for (int e = 0; e < 16; ++e) xb[n][e] = (v0 + e < vend) ? apply_chain(ch[n], xb[n][e]) : 0.f;
+        }
     }
 #pragma unroll
-    for (int e = 0; e < 16; ++e)
+    for (int m = 0; m < MT; ++m)
+      if (m < mt_valid) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+        for (int n = 0; n < NT; ++n)
+          if (n < nt_valid) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[m][e], xb[n][e], acc[m][n], 0, 0, 0);
+            for (int e = 0; e < 16; ++e) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[m][e], xb[n][e], acc[m][n], 0, 0, 0);
+          }
+      }
   }
   // cross-wave reduction; D row = co (4*lk + r), col = ci lj
   __shared__ float red[4][MT * NT * 4 * 64];
