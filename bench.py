@@ -127,6 +127,8 @@ def main():
     if mode == "auto":                      # big patches are GPU-bound either way; small ones are launch-bound without a graph
         mode = "eager" if V >= (1 << 20) else "graph"
 
+    ops.set_weight_grad_overlap(mode == "eager" and V >= (1 << 20))
+
     def eager_step():
         T.optimizer.zero_grad()
         T.optimization_loop()

@@ -268,8 +268,9 @@ def test_cli_end_to_end_single_and_multi_rank_driver_agree(tmp_path, monkeypatch
     np.testing.assert_allclose(rec_dev, rec_files, rtol=1e-5, atol=1e-5 * np.abs(rec_files).max())
 
 
-@pytest.mark.parametrize("shape,upsample", [((16, 24, 40), "linear"), ((13, 18, 21), "nearest")])
-def test_fused_block_nodes_match_leaf_by_leaf_execution(shape, upsample):
+@pytest.mark.parametrize("shape,upsample,overlap", [((16, 24, 40), "linear", False), ((13, 18, 21), "nearest", False),
+                                                    ((16, 24, 40), "linear", True)])
+def test_fused_block_nodes_match_leaf_by_leaf_execution(shape, upsample, overlap):
     """The fused autograd nodes (Block3dFn / ResPath3dFn / SkipJoinFn: zero-copy concat, chain-on-load, in-kernel gradient
     fan-in, forked BatchNorm-backward partials) against the same module tree executed leaf by leaf: same output, loss,
     parameter gradients and BatchNorm running statistics up to fp32 rounding."""
@@ -287,12 +288,15 @@ def test_fused_block_nodes_match_leaf_by_leaf_execution(shape, upsample):
     res = []
     for fused, n in ((True, net), (False, net2)):
         M.FUSE_BLOCKS = fused
+        ops.OVERLAP_WEIGHT_GRADS = overlap and fused      # weight gradients on the side stream (joined per node)
         try:
             out = n(z)
             loss, _ = ops.masked_loss(out, img, mask, "mse")
             loss.backward()
         finally:
             M.FUSE_BLOCKS = True
+            ops.OVERLAP_WEIGHT_GRADS = False
+        torch.cuda.synchronize()
         res.append((out.detach(), float(loss.detach()), {k: p.grad.detach() for k, p in n.named_parameters()},
                     {k: b.detach().clone() for k, b in n.named_buffers()}))
     (o1, l1, g1, b1), (o2, l2, g2, b2) = res
