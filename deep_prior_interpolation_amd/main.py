@@ -150,11 +150,14 @@ class Interpolator:
         mode "graph": iteration 0 runs eagerly, iteration 1 is captured into a hipGraph and replayed; history, best-output
         tracking, plateau LR and early stopping live on the device (dpi_loop_control / dpi_copy_if), the host only polls
         the `active` flag every `check_every` replays.  Same arithmetic, same stopping iteration.
-        "auto" picks "graph" unless per-iteration host work was requested (net_inputs, --save_every)."""
+        "auto" picks "graph" unless per-iteration host work was requested (net_inputs, --save_every) or the patch has
+        >= 2^20 voxels."""
         a = self.args
         if mode == "auto":
+            # big patches are GPU-bound either way and gain from overlapping the weight gradients (eager only);
+            # small ones are launch-bound without a graph
             mode = "eager" if (net_inputs is not None or a.save_every is not None or a.epochs < 3
-                               or a.data_forgetting_factor != 0) else "graph"
+                               or a.data_forgetting_factor != 0 or int(np.prod(self.img.shape[:-1])) >= (1 << 20)) else "graph"
         self.optimizer = FusedAdam(self.net.parameters(), lr=a.lr)
         ops.set_weight_grad_overlap(mode == "eager" and int(np.prod(self.img.shape[:-1])) >= (1 << 20))
         start = time()
