@@ -311,3 +311,42 @@ def test_fused_block_nodes_match_leaf_by_leaf_execution(shape, upsample, overlap
             assert int(b1[k]) == int(b2[k])
         else:
             assert rel(b1[k], b2[k].cpu().numpy()) < 1e-5
+
+
+def test_snr_parity_with_oracle_over_a_longer_run():
+    """SURVEY 8(d) SNR-parity protocol at test scale: same synthetic survey, same initial weights, the same per-iteration
+    noise stream (host generator) fed to the HIP engine and to the CPU oracle for 40 Adam iterations.  The problem is
+    chaotic (the reference does not reproduce its own trajectory across thread counts), so the bar
+    is: identical while rounding noise is still small (10 iterations), then the same loss level and recovered SNR."""
+    from deep_prior_interpolation_amd import utils as u
+    from deep_prior_interpolation_amd.main import Interpolator
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    from oracle import dpi_oracle as O
+    K, shape = 40, (24, 24, 32)
+    args = parse_arguments(["--imgdir", "x", "--datadim", "3d", "--filters", "4", "8", "16", "--skip", "4", "8", "--inputdepth", "8",
+                            "--upsample", "linear", "--epochs", str(K), "--gpu", "0", "--loss", "mae"])
+    vol = u.hyperbolic_volume(shape, seed=2)[..., None] * 40.0
+    mask = u.random_trace_mask(shape, 0.5, seed=3)[..., None].astype(np.float64)
+    u.set_seed(0)
+    T = Interpolator(args, "/tmp")
+    T.load_data({"image": vol, "mask": mask, "name": "0"})
+    T.build_model()
+    T.build_input()
+    init = {k: v.detach().cpu().numpy().copy() for k, v in T.net.state_dict().items()}
+    z = T.input_.detach().cpu()
+    inputs = [z + 0.03 * torch.randn(z.shape, generator=torch.Generator().manual_seed(100 + i)) for i in range(K)]
+    T.optimize(net_inputs=[t.to(T.device) for t in inputs], verbose=False)
+    S = O.NetState(init)
+    cfg = {"ndim": 3, "filters": [4, 8, 16], "skip": [4, 8], "upsample": "trilinear", "act": "LeakyReLU", "last_act": None}
+    h = O.optimize(S, cfg, z, T.img_.cpu(), T.mask_.cpu(), K, lr=args.lr, loss_kind="mae", net_inputs=inputs)
+    got, ref = np.array(T.history.loss), np.array(h["loss"])
+    err = np.abs(got - ref) / ref
+    print("relative loss error per iteration:", np.array2string(err, precision=1))
+    assert ref[-1] < 0.8 * ref[0]                                    # the run actually optimises something
+    # rounding differences (1e-7 at iteration 0) are amplified ~2x per iteration by the optimisation itself — the same
+    # happens between two CPU runs of the reference with different thread counts — so: tight while the trajectories are
+    # still the same trajectory, then agreement of the quantities the method is judged by
+    assert err[:10].max() < 1e-3, err[:10]
+    assert abs(got[-10:].mean() - ref[-10:].mean()) < 0.08 * ref[-10:].mean()
+    assert abs(max(T.history.snr) - max(h["snr"])) < 0.5
+    assert np.abs(np.array(T.history.snr)[:10] - np.array(h["snr"])[:10]).max() < 0.02
