@@ -124,6 +124,10 @@ __device__ __forceinline__ void stage_store(float* lds, const float (&sr)[4][G::
 // ---------------------------------------------------------------- forward / backward-data ---------------------------
 // WPE = waves per SIMD the register allocation is held to: 3 pays when Cin <= 8 (one or two chunks: the staging of a
 // tile is not hidden behind its own MFMAs, only behind other workgroups'), 2 (no cap) is faster for long channel loops.
+// PERSIST: the workgroup walks tiles vt = blockIdx.x, blockIdx.x + gridDim.x, ... and requests the first chunk (and, via
+// the plane-wise weight reload, the first weights) of its NEXT tile behind the last chunk's MFMAs of the current one, so
+// tile addressing, first-load latency and the epilogue's stores are no longer exposed once per tile (they are ~20 % of a
+// tile for Cin = 25 and more than half for Cin = 4 / 8).
 #ifdef DPI_TRACE
 __device__ long long g_blk[8192][4];
 __device__ long long g_trace[4][64];
@@ -131,44 +135,41 @@ __device__ long long g_trace[4][64];
 #else
 #define TR(i)
 #endif
-template <int KD, int NR, int NH, bool FLIP, int S = 1, int WPE = 2>
+template <int KD, int NR, int NH, bool FLIP, int S = 1, int WPE = 2, bool PERSIST = false>
 __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
-#ifdef DPI_TRACE
-  const int trc = blockIdx.y != 0 ? -1 : blockIdx.x == 0 ? 0 : blockIdx.x == 1 ? 1 : blockIdx.x == 2048 ? 2 : blockIdx.x == 4000 ? 3 : -1;
-  const int tid_ = threadIdx.x;
-  { const int tid = tid_; TR(0); }
-  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) {
-    g_blk[blockIdx.x][0] = wall_clock64();
-    g_blk[blockIdx.x][2] = __builtin_amdgcn_s_getreg(63492);
-    g_blk[blockIdx.x][3] = __builtin_amdgcn_s_getreg(63508);
-  }
-#endif
   using G = Geo<KD, NR, NH, S>;
   constexpr int TAPS = KD * 9;
   constexpr int PD = (KD - 1) / 2;
   constexpr int NT = NR * NH;                       // voxel tiles per wave
   __shared__ __attribute__((aligned(16))) float lds[4 * G::CS];
+  __shared__ double red[4][16][2];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lk = lane >> 4, lj = lane & 15;
-  const int tile_id = xcd_tile(blockIdx.x, gridDim.x);
-  int bt = tile_id;
-  const int tw_i = bt % a.ntw; bt /= a.ntw;
-  const int th_i = bt % a.nth; bt /= a.nth;
-  const int td_i = bt;
   const int n0 = blockIdx.y * 16;
-  const int od0 = td_i * G::TZ, oh0 = th_i * G::TY, ow0 = tw_i * G::TW;
   const size_t V = (size_t)a.D * a.H * a.W;
-
-  int goff[G::E], loff[G::E];
-  tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
+  const int ntiles = a.ntd * a.nth * a.ntw;
+  const int Do = (a.D + 2 * PD - KD) / G::SD + 1, Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
+  const size_t Vo = (size_t)Do * Ho * Wo;
+#ifdef DPI_TRACE
+  const int trc = blockIdx.y != 0 ? -1 : blockIdx.x == 0 ? 0 : blockIdx.x == 1 ? 1 : blockIdx.x == 300 ? 2 : blockIdx.x == 500 ? 3 : -1;
+  TR(0);
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 8192) {
+    g_blk[blockIdx.x][0] = wall_clock64();
+    g_blk[blockIdx.x][2] = __builtin_amdgcn_s_getreg(63492);
+    g_blk[blockIdx.x][3] = __builtin_amdgcn_s_getreg(63508);
+  }
+#endif
+  auto tile_origin = [&](int vt, int& tile_id, int& od0, int& oh0, int& ow0) {
+    tile_id = xcd_tile(vt, ntiles);
+    int bt = tile_id;
+    const int tw_i = bt % a.ntw; bt /= a.ntw;
+    const int th_i = bt % a.nth; bt /= a.nth;
+    od0 = bt * G::TZ; oh0 = th_i * G::TY; ow0 = tw_i * G::TW;
+  };
 
   const int wz = G::SLICES ? wid : 0, wh = G::SLICES ? 0 : wid * NR;
   const int lbase = lk * G::CS + wz * G::SD * G::DS + wh * S * G::RS + lj * S;
-
-  f32x4 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // weights of a 4-channel chunk: lane (co = lj, ci = lk) keeps its TAPS filter taps.
   // The taps of depth plane kd are dead once that plane's steps are done, so the NEXT chunk's weights replace them plane
@@ -192,7 +193,11 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
     for (int t = 0; t < 9; ++t) wr[kd * 9 + t] = ok ? wn[t] : 0.f;
   };
 
+  int goff[G::E], loff[G::E];
   float wr[TAPS], wn[9], sr[4][G::E];
+  int vt = blockIdx.x, tile_id, od0, oh0, ow0;
+  tile_origin(vt, tile_id, od0, oh0, ow0);
+  tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
   stage_load<G>(sr, a.x, a.Cin, V, 0, goff);
   {
     bool ok;
@@ -202,122 +207,134 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) wr[t] = ok ? wr[t] : 0.f;
   }
-  if (a.accumulate) {
-    // gradient fan-in: start the accumulators from the destination (loads overlap the first chunk's staging)
-    const int Do_ = (a.D + 2 * PD - KD) / G::SD + 1, Ho_ = (a.H - 1) / S + 1, Wo_ = (a.W - 1) / S + 1;
-    const size_t Vo_ = (size_t)Do_ * Ho_ * Wo_;
+
+  for (;;) {
+    const int vt_next = vt + (int)gridDim.x;
+    const bool has_next = PERSIST && vt_next < ntiles;
+    int tile_n = 0, od_n = 0, oh_n = 0, ow_n = 0;
+    if (has_next) tile_origin(vt_next, tile_n, od_n, oh_n, ow_n);
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.accumulate) {
+      // gradient fan-in: start the accumulators from the destination (loads overlap the first chunk's staging)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = n0 + 4 * lk + r;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
+          if (co < a.Cout && od < Do && oh < Ho && ow < Wo) acc[t][r] = a.y[(size_t)co * Vo + ((size_t)od * Ho + oh) * Wo + ow];
+        }
+      }
+    }
+
+    TR(1);
+    for (int c0 = 0; c0 < a.Cin; c0 += 4) {
+      __syncthreads();                                   // everyone is done reading the previous chunk
+      TR(2 + (c0 / 4) * 4);
+      stage_store<G>(lds, sr, a.chain, a.Cin, c0, goff, loff);
+      TR(3 + (c0 / 4) * 4);
+      __syncthreads();
+      TR(4 + (c0 / 4) * 4);
+      const bool more = c0 + 4 < a.Cin;
+      if (more) stage_load<G>(sr, a.x, a.Cin, V, c0 + 4, goff);   // prefetch the next chunk behind this chunk's MFMAs
+      else if (has_next) {                                        // ... or the first chunk of the next tile
+        tile_slots<G>(tid, od_n * G::SD - PD, oh_n * S - 1, ow_n * S - 1, a.D, a.H, a.W, goff, loff);
+        stage_load<G>(sr, a.x, a.Cin, V, 0, goff);
+      }
+      // software-pipelined walk over (kd, input row): LDS values of step s+1 are requested before the MFMAs of step s
+      float bc[G::NB], bn[G::NB];
+      auto load_b = [&](float (&b)[G::NB], int step) {
+        const int kd = step / G::NROW, ir = step % G::NROW;
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) b[h * 3 + kw] = lds[lbase + kd * G::DS + ir * G::RS + h * 16 * S + kw];
+      };
+      load_b(bc, 0);
+      const int cn = more ? c0 + 4 : 0;                  // chunk whose weights are fetched next (chunk 0: next tile / harmless)
+#pragma unroll
+      for (int step = 0; step < G::NSTEP; ++step) {
+        const int kd = step / G::NROW, ir = step % G::NROW;
+        if (step + 1 < G::NSTEP) load_b(bn, step + 1);
+        if (ir == 0) load_w_raw(wn, cn, kd);
+        // keep the requests above AHEAD of this step's MFMAs (the scheduler otherwise sinks every ds_read to just before
+        // its first use and the wave then waits out the full LDS latency ~27 times per chunk)
+        if (WPE <= 2) __builtin_amdgcn_sched_barrier(0);
+        // kw outermost: consecutive MFMAs go to DIFFERENT accumulators (a dependent 16x16x4 f32 MFMA needs 40 cycles,
+        // an independent one issues every 32)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            const int hr = (ir - kh) / S;                // output row fed by this input row through tap kh
+            if (ir - kh >= 0 && (ir - kh) % S == 0 && hr < NR) {
+#pragma unroll
+              for (int h = 0; h < NH; ++h)
+                acc[hr * NH + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(kd * 3 + kh) * 3 + kw], bc[h * 3 + kw], acc[hr * NH + h], 0, 0, 0);
+            }
+          }
+        if (WPE <= 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G::NB; ++i) bc[i] = bn[i];
+        if (ir == G::NROW - 1) commit_w(wr, wn, cn, kd);
+      }
+      TR(5 + (c0 / 4) * 4);
+    }
+    TR(40);
+
+    // ---- epilogue: D row = co (4*lk + r), D col = voxel lj -----------------------------------------------------------
+    // interior tile with a full channel tile (the common case): no per-element bounds tests, one base pointer per row r
+    const bool interior = od0 + G::TZ <= Do && oh0 + G::TY <= Ho && ow0 + G::TW <= Wo && n0 + 16 <= a.Cout;
+    const int vbase = ((od0 + wz) * Ho + oh0 + wh) * Wo + ow0 + lj;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int co = n0 + 4 * lk + r;
+      const bool cok = co < a.Cout;
+      const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
+      float* __restrict__ yc = a.y + (size_t)(cok ? co : 0) * Vo + vbase;
+      double s = 0.0, q = 0.0;
+      if (interior) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
-        if (co < a.Cout && od < Do_ && oh < Ho_ && ow < Wo_) acc[t][r] = a.y[(size_t)co * Vo_ + ((size_t)od * Ho_ + oh) * Wo_ + ow];
-      }
-    }
-  }
-
-  TR(1);
-  for (int c0 = 0; c0 < a.Cin; c0 += 4) {
-    __syncthreads();                                     // everyone is done reading the previous chunk
-    TR(2 + (c0 / 4) * 4);
-    stage_store<G>(lds, sr, a.chain, a.Cin, c0, goff, loff);
-    TR(3 + (c0 / 4) * 4);
-    __syncthreads();
-    TR(4 + (c0 / 4) * 4);
-    const bool more = c0 + 4 < a.Cin;
-    if (more) stage_load<G>(sr, a.x, a.Cin, V, c0 + 4, goff);   // prefetch the next chunk behind this chunk's MFMAs
-    // software-pipelined walk over (kd, input row): LDS values of step s+1 are requested before the MFMAs of step s
-    float bc[G::NB], bn[G::NB];
-    auto load_b = [&](float (&b)[G::NB], int step) {
-      const int kd = step / G::NROW, ir = step % G::NROW;
-#pragma unroll
-      for (int h = 0; h < NH; ++h)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) b[h * 3 + kw] = lds[lbase + kd * G::DS + ir * G::RS + h * 16 * S + kw];
-    };
-    load_b(bc, 0);
-    const int cn = more ? c0 + 4 : c0;                   // chunk whose weights are fetched next (a harmless re-read at the end)
-#pragma unroll
-    for (int step = 0; step < G::NSTEP; ++step) {
-      const int kd = step / G::NROW, ir = step % G::NROW;
-      if (step + 1 < G::NSTEP) load_b(bn, step + 1);
-      if (ir == 0) load_w_raw(wn, cn, kd);
-      // keep the requests above AHEAD of this step's MFMAs (the scheduler otherwise sinks every ds_read to just before
-      // its first use and the wave then waits out the full LDS latency ~27 times per chunk)
-      if (WPE <= 2) __builtin_amdgcn_sched_barrier(0);
-      // kw outermost: consecutive MFMAs go to DIFFERENT accumulators (a dependent 16x16x4 f32 MFMA needs 40 cycles,
-      // an independent one issues every 32)
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const int hr = (ir - kh) / S;                  // output row fed by this input row through tap kh
-          if (ir - kh >= 0 && (ir - kh) % S == 0 && hr < NR) {
-#pragma unroll
-            for (int h = 0; h < NH; ++h)
-              acc[hr * NH + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(kd * 3 + kh) * 3 + kw], bc[h * 3 + kw], acc[hr * NH + h], 0, 0, 0);
-          }
-        }
-      if (WPE <= 2) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < G::NB; ++i) bc[i] = bn[i];
-      if (ir == G::NROW - 1) commit_w(wr, wn, cn, kd);
-    }
-    TR(5 + (c0 / 4) * 4);
-  }
-  TR(40);
-
-  // ---- epilogue: D row = co (4*lk + r), D col = voxel lj -----------------------------------------------------------
-  const int Do = (a.D + 2 * PD - KD) / G::SD + 1, Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
-  const size_t Vo = (size_t)Do * Ho * Wo;
-  __shared__ double red[4][16][2];
-  // interior tile with a full channel tile (the common case): no per-element bounds tests, one base pointer per row r
-  const bool interior = od0 + G::TZ <= Do && oh0 + G::TY <= Ho && ow0 + G::TW <= Wo && n0 + 16 <= a.Cout;
-  const int vbase = ((od0 + wz) * Ho + oh0 + wh) * Wo + ow0 + lj;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int co = n0 + 4 * lk + r;
-    const bool cok = co < a.Cout;
-    const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
-    float* __restrict__ yc = a.y + (size_t)(cok ? co : 0) * Vo + vbase;
-    double s = 0.0, q = 0.0;
-    if (interior) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float v = acc[t][r] + bv;
-        yc[(t / NH) * Wo + (t % NH) * 16] = v;
-        if (a.partials) { s += v; q += (double)v * v; }
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
-        if (cok && od < Do && oh < Ho && ow < Wo) {
+        for (int t = 0; t < NT; ++t) {
           const float v = acc[t][r] + bv;
           yc[(t / NH) * Wo + (t % NH) * 16] = v;
-          s += v;
-          q += (double)v * v;
+          if (a.partials) { s += v; q += (double)v * v; }
         }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
+          if (cok && od < Do && oh < Ho && ow < Wo) {
+            const float v = acc[t][r] + bv;
+            yc[(t / NH) * Wo + (t % NH) * 16] = v;
+            s += v;
+            q += (double)v * v;
+          }
+        }
+      }
+      if (a.partials) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if (lj == 0) { red[wid][4 * lk + r][0] = s; red[wid][4 * lk + r][1] = q; }
       }
     }
     if (a.partials) {
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-      if (lj == 0) { red[wid][4 * lk + r][0] = s; red[wid][4 * lk + r][1] = q; }
+      __syncthreads();
+      if (tid < 32) {
+        const int c = tid >> 1, which = tid & 1;
+        const double rsum = red[0][c][which] + red[1][c][which] + red[2][c][which] + red[3][c][which];
+        if (n0 + c < a.Cout) a.partials[((size_t)tile_id * a.Cout + n0 + c) * 2 + which] = rsum;
+      }
     }
+    TR(41);
+    if (!has_next) break;
+    vt = vt_next; tile_id = tile_n; od0 = od_n; oh0 = oh_n; ow0 = ow_n;
   }
-  if (a.partials) {
-    __syncthreads();
-    if (tid < 32) {
-      const int c = tid >> 1, which = tid & 1;
-      const double rsum = red[0][c][which] + red[1][c][which] + red[2][c][which] + red[3][c][which];
-      if (n0 + c < a.Cout) a.partials[((size_t)tile_id * a.Cout + n0 + c) * 2 + which] = rsum;
-    }
-  }
-  TR(41);
 #ifdef DPI_TRACE
-  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) g_blk[blockIdx.x][1] = wall_clock64();
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 8192) g_blk[blockIdx.x][1] = wall_clock64();
 #endif
 }
 
@@ -805,8 +822,17 @@ static void launch_variant(const MArgs& a, int nr, int nh, int stride, dim3 grid
     }
     return;
   }
-  if (nr == 8 && a.Cin <= 8) conv_mfma_kernel<KD, 8, 2, FLIP, 1, 3><<<grid, 256, 0, st>>>(a);
-  else if (nr == 8) conv_mfma_kernel<KD, 8, 2, FLIP><<<grid, 256, 0, st>>>(a);
+  if (nr == 8) {
+    // persistent workgroups: 2 per CU, a multiple of 8 so that a workgroup's
+    // tiles stay on its XCD; fewer tiles than that -> one tile per workgroup as before
+    static const bool persist = getenv("DPI_NO_PERSIST") == nullptr;
+    dim3 pg = grid;
+    if (a.Cin <= 8) conv_mfma_kernel<KD, 8, 2, FLIP, 1, 3><<<grid, 256, 0, st>>>(a);   // occupancy 3 beats persistence here (measured)
+    else {
+      if (persist && grid.x > 512) pg.x = 512;        // 2 workgroups per CU (256 VGPRs)
+      conv_mfma_kernel<KD, 8, 2, FLIP, 1, 2, true><<<pg, 256, 0, st>>>(a);
+    }
+  }
   else if (nh == 2) conv_mfma_kernel<KD, 2, 2, FLIP><<<grid, 256, 0, st>>>(a);
   else conv_mfma_kernel<KD, 2, 1, FLIP><<<grid, 256, 0, st>>>(a);
 }
