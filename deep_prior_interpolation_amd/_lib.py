@@ -89,6 +89,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise DpiError("libdpi_hip.so not found at %s — run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    # torch first: libdpi_hip.so must bind to the HIP runtime torch already loaded (its bundled libamdhip64).  Loaded the
+    # other way round the process ends up with two runtimes and launches fail with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:
