@@ -76,3 +76,37 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     for (int i = 0; i < nw; ++i) r += sh[i];
   return r;
 }
+
+// Final reduction over chunks, deterministic (fixed order).  A workgroup owns OB consecutive outputs x (256 / OB) chunk
+// groups: thread (o, g) sums chunks g, g + NG, ... of output o with coalesced rows (the earlier 8-lanes-per-output layout
+// read 32-byte pieces of 8 different chunk rows per instruction), 4 loads in flight, then the group sums are added in
+// order through LDS.  OB = 64 normally, 16 when there are few outputs and many chunks (more groups, shorter chains).
+template <int OB>
+__global__ __launch_bounds__(256) void dpi_reduce_chunks_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n, int nchunks) {
+  constexpr int NG = 256 / OB;
+  __shared__ float part[NG][OB];
+  const int o = threadIdx.x % OB, g = threadIdx.x / OB;
+  const size_t i = (size_t)blockIdx.x * OB + o;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int c = g;
+    for (; c + 3 * NG < nchunks; c += 4 * NG) {
+      s0 += ws[(size_t)c * n + i]; s1 += ws[(size_t)(c + NG) * n + i];
+      s2 += ws[(size_t)(c + 2 * NG) * n + i]; s3 += ws[(size_t)(c + 3 * NG) * n + i];
+    }
+    for (; c < nchunks; c += NG) s0 += ws[(size_t)c * n + i];
+  }
+  part[g][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && i < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) s += part[k][o];
+    out[i] = s;
+  }
+}
+static inline void dpi_reduce_chunks(const float* ws, float* out, size_t n, int nchunks, hipStream_t st) {
+  if (n < 8192 && nchunks > 64) dpi_reduce_chunks_kernel<16><<<(unsigned)cdivz(n, 16), 256, 0, st>>>(ws, out, n, nchunks);
+  else dpi_reduce_chunks_kernel<64><<<(unsigned)cdivz(n, 64), 256, 0, st>>>(ws, out, n, nchunks);
+}
+

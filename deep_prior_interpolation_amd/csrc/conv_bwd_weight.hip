@@ -349,6 +349,6 @@ extern "C" int dpi_conv_bwd_weight(const dpi_conv_desc* d, const float* x, const
     }
   }
   if (int e = dpi_check_launch("conv_bwd_weight")) return e;
-  reduce_chunks_kernel<<<(unsigned)cdivz(per * 8, 256), 256, 0, st>>>(ws, dw, per, p.nchunks);
+  dpi_reduce_chunks(ws, dw, per, p.nchunks, st);
   return dpi_check_launch("reduce_chunks");
 }

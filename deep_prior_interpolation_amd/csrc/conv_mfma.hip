@@ -778,18 +778,6 @@ __global__ __launch_bounds__(256) void conv_bwd_data_s2_mfma_kernel(BdS2Args a) 
   }
 }
 
-// 8 lanes per output element: lane p sums chunks p, p+8, ... in order, then a fixed xor tree (deterministic)
-__global__ void reduce_chunks2_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n, int nchunks) {
-  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t i = gid >> 3;
-  const int part = gid & 7;
-  float s = 0.f;
-  if (i < n)
-    for (int c = part; c < nchunks; c += 8) s += ws[(size_t)c * n + i];
-  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-  if (i < n && part == 0) out[i] = s;
-}
-
 }  // namespace
 
 // ---- host-side entry points used by the dispatchers in conv_direct.hip / conv_bwd_weight.hip ---------------------------
@@ -910,7 +898,7 @@ int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const f
   }
   if (int e = dpi_check_launch("conv_bwd_weight_mfma")) return e;
   const size_t per = (size_t)d->Cout * d->Cin * d->kd * 9;
-  reduce_chunks2_kernel<<<(unsigned)cdivz(per * 8, 256), 256, 0, st>>>(ws, dw, per, p.nchunks);
+  dpi_reduce_chunks(ws, dw, per, p.nchunks, st);
   return dpi_check_launch("reduce_chunks");
 }
 
@@ -952,6 +940,6 @@ int dpi_conv_bwd_weight_smallco_run(const dpi_conv_desc* d, const float* x, cons
   conv_bwd_weight_smallco_kernel<<<dim3(p.nchunks, cdiv(d->Cin, 6)), 256, 0, st>>>(a);
   if (int e = dpi_check_launch("conv_bwd_weight_smallco")) return e;
   const size_t per = (size_t)d->Cout * d->Cin * 27;
-  reduce_chunks2_kernel<<<(unsigned)cdivz(per * 8, 256), 256, 0, st>>>(ws, dw, per, p.nchunks);
+  dpi_reduce_chunks(ws, dw, per, p.nchunks, st);
   return dpi_check_launch("reduce_chunks");
 }

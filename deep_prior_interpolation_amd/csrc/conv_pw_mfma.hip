@@ -347,6 +347,6 @@ int dpi_conv_pw_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, cons
   }
   if (int e = dpi_check_launch("conv_pw_bwd_weight_mfma")) return e;
   const size_t per = (size_t)d->Cout * d->Cin;
-  reduce_chunks_pw_kernel<<<(unsigned)cdivz(per * 8, 256), 256, 0, st>>>(ws, dw, per, p.nchunks);
+  dpi_reduce_chunks(ws, dw, per, p.nchunks, st);
   return dpi_check_launch("reduce_chunks_pw");
 }
