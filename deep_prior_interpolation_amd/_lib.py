@@ -57,7 +57,8 @@ SIGNATURES = {
     "dpi_add": (_I, [_P, _P, _Z, _P, _P]),
     "dpi_channel_sum": (_I, [_P, _I, _Z, _P, _P, _P]),
     "dpi_upsample2x_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
-    "dpi_upsample2x_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "dpi_upsample2x_bwd_ws_floats": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I]),
+    "dpi_upsample2x_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "dpi_crop_copy": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dpi_crop_copy_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dpi_maxpool2x2_fwd": (_I, [_P, _I, _I, _I, _P, _P]),

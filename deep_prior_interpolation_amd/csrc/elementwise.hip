@@ -592,6 +592,25 @@ __global__ __launch_bounds__(256) void upsample_lin_bwd_gather_kernel(const floa
   }
 }
 
+// Separable adjoint, one axis per pass: in [outer][no][inner] -> out [outer][n][inner],
+//   out[i] = .25 in[2i-1] + .75 in[2i] + .75 in[2i+1] + .25 in[2i+2]   (edge weights 1 at i = 0 / n-1, taps >= no dropped).
+// Three coalesced passes (W, H, D) move 2.6x the gradient once instead of gathering 64 strided values per voxel
+// (8 L1 requests per voxel): 0.95 -> ~0.5 ms for the 51-channel full-resolution tensor.
+__global__ __launch_bounds__(256) void upsample_lin_bwd_axis_kernel(const float* __restrict__ in, float* __restrict__ out, size_t outer,
+                                                                    int n, int no, size_t inner) {
+  const size_t total = outer * n * inner;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t in_i = e % inner;
+    const int i = (int)((e / inner) % n);
+    const size_t o = e / (inner * n);
+    int oo[4];
+    float wt[4];
+    lin_bwd_taps(i, n, no, oo, wt);
+    const float* __restrict__ p = in + o * no * inner + in_i;
+    out[e] = (wt[0] * p[oo[0] * inner] + wt[1] * p[oo[1] * inner]) + (wt[2] * p[oo[2] * inner] + wt[3] * p[oo[3] * inner]);
+  }
+}
+
 __global__ __launch_bounds__(256) void crop_copy_kernel(const float* __restrict__ x, int D, int H, int W, int od, int oh, int ow,
                                                         int Do, int Ho, int Wo, float* __restrict__ y, int adjoint) {
   // forward: y[c][Do][Ho][Wo] = x[c][od+.., oh+.., ow+..]; adjoint: x-shaped output, zero outside the window
@@ -757,11 +776,27 @@ extern "C" int dpi_upsample2x_fwd(const float* x, const float* chain, int C, int
   return dpi_check_launch("upsample_fwd");
 }
 
+extern "C" size_t dpi_upsample2x_bwd_ws_floats(int C, int D, int H, int W, int Do, int Ho, int Wo, int linear) {
+  if (!linear || C <= 0) return 0;
+  const int scale_d = !(D == 1 && Do == 1);
+  return (size_t)C * Do * Ho * W + (scale_d ? (size_t)C * Do * H * W : 0);
+}
+
 extern "C" int dpi_upsample2x_bwd(const float* dy, int C, int D, int H, int W, int Do, int Ho, int Wo, int linear, float* dx,
-                                  void* stream) {
+                                  float* ws, void* stream) {
   DPI_REQUIRE(dy && dx && C > 0 && D > 0 && H > 0 && W > 0, "upsample_bwd: bad argument");
   const int scale_d = !(D == 1 && Do == 1);
   const size_t V = (size_t)D * H * W;
+  if (linear && ws) {                                   // separable passes through the caller's workspace
+    hipStream_t st = (hipStream_t)stream;
+    float* t1 = ws;                                     // [C][Do][Ho][W]
+    float* t2 = ws + (size_t)C * Do * Ho * W;           // [C][Do][H][W]
+    const size_t n1 = (size_t)C * Do * Ho * W, n2 = (size_t)C * Do * H * W;
+    upsample_lin_bwd_axis_kernel<<<ew_blocks(n1), 256, 0, st>>>(dy, t1, (size_t)C * Do * Ho, W, Wo, 1);
+    upsample_lin_bwd_axis_kernel<<<ew_blocks(n2), 256, 0, st>>>(t1, scale_d ? t2 : dx, (size_t)C * Do, H, Ho, W);
+    if (scale_d) upsample_lin_bwd_axis_kernel<<<ew_blocks((size_t)C * V), 256, 0, st>>>(t2, dx, C, D, Do, (size_t)H * W);
+    return dpi_check_launch("upsample_lin_bwd_axis");
+  }
   if (linear) {
     if (scale_d) upsample_lin_bwd_gather_kernel<true><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, dx);
     else upsample_lin_bwd_gather_kernel<false><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, dx);

@@ -183,6 +183,13 @@ def raw_bn_finalize(part, nblk, C_, count, gamma, beta, slope, running_mean, run
           "dpi_bn_finalize")
 
 
+def raw_upsample2x_bwd(dy, C_, D, H, W, Do, Ho, Wo, linear, dx):
+    L = _lib.load()
+    n = L.dpi_upsample2x_bwd_ws_floats(C_, D, H, W, Do, Ho, Wo, linear)
+    ws = torch.empty(n, dtype=torch.float32, device=dy.device) if n else None
+    check(L.dpi_upsample2x_bwd(ptr(dy), C_, D, H, W, Do, Ho, Wo, linear, ptr(dx), ptr(ws), stream()), "dpi_upsample2x_bwd")
+
+
 def raw_chain_apply(x, chain, C_, V, y):
     L = _lib.load()
     check(L.dpi_chain_apply(ptr(x), ptr(chain), C_, V, ptr(y), stream()), "dpi_chain_apply")
@@ -628,8 +635,7 @@ class SkipJoinFn(torch.autograd.Function):
         ddeep = None
         if ctx.needs_input_grad[1]:
             ddeep = torch.empty(deep_shape, dtype=torch.float32, device=dcat.device)
-            check(L.dpi_upsample2x_bwd(ptr(dcat[:, Cs:]), Cd, Dd, Hd, Wd, Do, Ho, Wo, linear, ptr(ddeep), stream()),
-                  "dpi_upsample2x_bwd")
+            raw_upsample2x_bwd(dcat[:, Cs:], Cd, Dd, Hd, Wd, Do, Ho, Wo, linear, ddeep)
         dt, dgB, deB, (red3, red1) = _bn_backward_fork(dcat[:, :Cs], t, miB, gB, eB, slope, 1.0,
                                                        [(r3, mi3, g3, e3, None, slope), (r1, mi1, g1, e1, None, slope)])
         dr3, dg3, de3 = _bn_backward_apply(dt, r3, mi3, g3, e3, 1.0, slope, red3)
@@ -707,7 +713,7 @@ class Upsample2xFn(torch.autograd.Function):
         dy = _req(dy, "upsample grad")
         C_, D, H, W, Do, Ho, Wo, linear = ctx.geo
         dx = torch.empty(ctx.in_shape, dtype=torch.float32, device=dy.device)
-        check(_lib.load().dpi_upsample2x_bwd(ptr(dy), C_, D, H, W, Do, Ho, Wo, linear, ptr(dx), stream()), "dpi_upsample2x_bwd")
+        raw_upsample2x_bwd(dy, C_, D, H, W, Do, Ho, Wo, linear, dx)
         return dx, None, None
 
 

@@ -146,8 +146,11 @@ int dpi_channel_sum(const float* x, int C, size_t V, double* ws, float* out, voi
  */
 int dpi_upsample2x_fwd(const float* x, const float* chain, int C, int D, int H, int W, int Do, int Ho,
                        int Wo, int linear, float* y, void* stream);
+/* ws (optional, linear only): dpi_upsample2x_bwd_ws_floats floats; with it the adjoint runs as three separable,
+ * coalesced passes (W, H, D) instead of a 64-tap gather per voxel.  NULL = gather. */
+size_t dpi_upsample2x_bwd_ws_floats(int C, int D, int H, int W, int Do, int Ho, int Wo, int linear);
 int dpi_upsample2x_bwd(const float* dy, int C, int D, int H, int W, int Do, int Ho, int Wo, int linear,
-                       float* dx, void* stream);
+                       float* dx, float* ws, void* stream);
 /* centre-crop copy [C][D][H][W] -> [C][Do][Ho][Wo] starting at (od,oh,ow); and its adjoint (zero-fill) */
 int dpi_crop_copy(const float* x, int C, int D, int H, int W, int od, int oh, int ow, int Do, int Ho,
                   int Wo, float* y, void* stream);
