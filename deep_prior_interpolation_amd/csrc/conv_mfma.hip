@@ -716,25 +716,39 @@ __global__ __launch_bounds__(256) void conv_bwd_data_s2_mfma_kernel(BdS2Args a) 
   for (int c = 0; c < NCLS; ++c) { acc[c][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[c][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
   const int ci_w = n0 + lj;
+  // register prefetch of the next 4-channel chunk (weights + dy halo tile) behind this chunk's MFMAs: with 54 MFMAs per
+  // chunk the two global round trips per chunk otherwise dominate the kernel
+  float wn[TAPS], sr[4][E];
+  auto fetch = [&](int c0) {
+    const int co = c0 + lk;
+    const bool ok = ci_w < a.Cin && co < a.Cout;
+    const float* __restrict__ wp = a.w + ((size_t)(ok ? co : 0) * a.Cin + (ok ? ci_w : 0)) * TAPS;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) wn[t] = wp[t];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // channels past Cout re-read the last one: their weights are zero
+      const __amdgpu_buffer_rsrc_t r = dpi_buffer(a.dy + (size_t)min(c0 + c, a.Cout - 1) * Vo, Vo * sizeof(float));
+#pragma unroll
+      for (int e = 0; e < E; ++e) sr[c][e] = dpi_buffer_load(r, goff[e] * 4);      // outside the tile / volume -> 0
+    }
+  };
+  fetch(0);
   for (int c0 = 0; c0 < a.Cout; c0 += 4) {
     float wr[TAPS];
     {
-      const int co = c0 + lk;
-      const bool ok = ci_w < a.Cin && co < a.Cout;
-      const float* __restrict__ wp = a.w + ((size_t)(ok ? co : 0) * a.Cin + (ok ? ci_w : 0)) * TAPS;
+      const bool ok = ci_w < a.Cin && c0 + lk < a.Cout;
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) wr[t] = ok ? wp[t] : 0.f;
+      for (int t = 0; t < TAPS; ++t) wr[t] = ok ? wn[t] : 0.f;
     }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int co = c0 + c;
-      const float* __restrict__ gc = a.dy + (size_t)(co < a.Cout ? co : 0) * Vo;
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int e = 0; e < E; ++e)
-        if (loff[e] >= 0) lds[c * CS + loff[e]] = (co < a.Cout && goff[e] >= 0) ? gc[goff[e]] : 0.f;
-    }
+        if ((e + 1) * 256 <= TILE || loff[e] >= 0) lds[c * CS + loff[e]] = sr[c][e];
     __syncthreads();
+    if (c0 + 4 < a.Cout) fetch(c0 + 4);
     // every (shift_d, shift_h, shift_w, row) sample of the tile feeds the classes whose parity allows that shift
 #pragma unroll
     for (int sd = 0; sd < ID; ++sd)
