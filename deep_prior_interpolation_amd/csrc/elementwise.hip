@@ -710,7 +710,10 @@ extern "C" int dpi_bn_bwd_apply(const float* dy, const float* x, const float* me
                                 size_t V, float* dx, float* dgamma, float* dbeta, void* stream) {
   DPI_REQUIRE(dy && x && mean_invstd && partials && dx && C > 0 && V > 0 && nblk > 0, "bn_bwd_apply: bad argument");
   DPI_REQUIRE(!in_chain || pre_slope == 1.f, "bn_bwd_apply: in_chain excludes pre_slope");
-  bn_bwd_apply_kernel<<<dim3(ew_blocks(cdivz(V, 4)), C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, beta, in_chain, pre_slope,
+  // every workgroup first re-reduces the phase-1 partials of its channel (nblk double pairs): keep >= 8 float4 per thread
+  // behind that prologue instead of one
+  unsigned gx = ew_blocks(cdivz(V, 4 * 8));
+  bn_bwd_apply_kernel<<<dim3(gx, C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, beta, in_chain, pre_slope,
                                                                                       post_slope, partials, nblk, C, V, dx, dgamma,
                                                                                       dbeta);
   return dpi_check_launch("bn_bwd_apply");
