@@ -52,6 +52,7 @@ SIGNATURES = {
     "dpi_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _P, _I, _I, _Z, _P, _P, _P, _P]),
     "dpi_bn_bwd_apply_fork": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _P, _I, _I, _Z, _P, _P, _P,
                                    _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
+    "dpi_bn_bwd_apply_dual": (_I, [_P, _I, _I, _Z] + [_P, _P, _P, _P, _P, _F, _P, _P, _P, _P] * 2 + [_I, _I, _P, _P, _P, _F, _P, _P]),
     "dpi_chain_add_stats": (_I, [_P, _P, _P, _P, _I, _Z, _F, _P, _P, _P]),
     "dpi_lrelu_bwd": (_I, [_P, _P, _F, _Z, _P, _P]),
     "dpi_add": (_I, [_P, _P, _Z, _P, _P]),

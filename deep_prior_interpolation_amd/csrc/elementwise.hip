@@ -372,6 +372,104 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fork_kernel(const float* __r
   }
 }
 
+// ---- two BatchNorm backward phase-2 passes that share their incoming gradient, in one pass ------------------------------
+// (the two branches of a residual join: shortcut-BN and bn1 of Block3d, the two conv-BNs of ResPath3d).  Optionally the
+// phase-1 partials of ONE more BatchNorm fed by dxb on the channel range [f_lo, f_hi) are taken on the fly (the third
+// conv-BN of Block3d: its input gradient is exactly bn1's dx on those channels, nothing accumulates into it later).
+struct BnSide {
+  const float* x;
+  const float* mean_invstd;
+  const float* gamma;
+  const float* beta;
+  const float* in_chain;
+  float post;
+  const double* partials;    // phase-1 partials of this BatchNorm, [nblk_in][C][2]
+  float* dx;
+  float* dgamma;
+  float* dbeta;
+};
+__global__ __launch_bounds__(256) void bn_bwd_apply_dual_kernel(const float* __restrict__ dy, BnSide A, BnSide B, int nblk_in, int C, size_t V,
+                                                                int nblk, int f_lo, int f_hi, const float* __restrict__ f_mi,
+                                                                const float* __restrict__ f_gamma, const float* __restrict__ f_beta,
+                                                                float f_post, double* __restrict__ f_partials) {
+  const int c = blockIdx.y, b = blockIdx.x;
+  __shared__ double tot[4];
+  if (threadIdx.x < 64) {
+    double sa = 0.0, qa = 0.0, sb = 0.0, qb = 0.0;
+    for (int i = threadIdx.x; i < nblk_in; i += 64) {
+      sa += A.partials[((size_t)i * C + c) * 2 + 0]; qa += A.partials[((size_t)i * C + c) * 2 + 1];
+      sb += B.partials[((size_t)i * C + c) * 2 + 0]; qb += B.partials[((size_t)i * C + c) * 2 + 1];
+    }
+    sa = wave_sum(sa); qa = wave_sum(qa); sb = wave_sum(sb); qb = wave_sum(qb);
+    if (threadIdx.x == 0) { tot[0] = sa; tot[1] = qa; tot[2] = sb; tot[3] = qb; }
+  }
+  __syncthreads();
+  const BnBwd ka = bn_bwd_consts(A.mean_invstd, A.gamma, A.beta, A.in_chain, 1.f, A.post, C, c);
+  const BnBwd kb = bn_bwd_consts(B.mean_invstd, B.gamma, B.beta, B.in_chain, 1.f, B.post, C, c);
+  const float a1 = (float)(tot[0] / (double)V), a2 = (float)(tot[1] / (double)V);
+  const float b1 = (float)(tot[2] / (double)V), b2 = (float)(tot[3] / (double)V);
+  if (b == 0 && threadIdx.x == 0) {
+    if (A.dgamma) A.dgamma[c] = (float)tot[1];
+    if (A.dbeta) A.dbeta[c] = (float)tot[0];
+    if (B.dgamma) B.dgamma[c] = (float)tot[3];
+    if (B.dbeta) B.dbeta[c] = (float)tot[2];
+  }
+  const bool forked = f_partials && c >= f_lo && c < f_hi;
+  const int fc = forked ? c - f_lo : 0, fC = f_hi - f_lo;
+  const BnBwd kf = forked ? bn_bwd_consts(f_mi, f_gamma, f_beta, nullptr, 1.f, f_post, fC, fc) : ka;
+  const size_t span = stat_span(V, nblk);
+  const size_t beg = (size_t)b * span, end = beg + span < V ? beg + span : V;
+  const float* __restrict__ gc = dy + (size_t)c * V;
+  const float* __restrict__ xa = A.x + (size_t)c * V;
+  const float* __restrict__ xb = B.x + (size_t)c * V;
+  float* __restrict__ oa = A.dx + (size_t)c * V;
+  float* __restrict__ ob = B.dx + (size_t)c * V;
+  double sf = 0.0, qf = 0.0;
+  const bool vec = (V & 3) == 0;
+  for (size_t i = beg + (size_t)threadIdx.x * 4; i < end; i += 1024) {
+    float gv[4], av[4], bv[4], ra[4], rb[4];
+    if (vec) {
+      const float4 g = *reinterpret_cast<const float4*>(gc + i);
+      const float4 t = *reinterpret_cast<const float4*>(xa + i);
+      const float4 u = *reinterpret_cast<const float4*>(xb + i);
+      gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
+      av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+      bv[0] = u.x; bv[1] = u.y; bv[2] = u.z; bv[3] = u.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool in = i + j < end;
+        gv[j] = in ? gc[i + j] : 0.f; av[j] = in ? xa[i + j] : 0.f; bv[j] = in ? xb[i + j] : 0.f;
+      }
+    }
+    float lsf = 0.f, lqf = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float xh, g;
+      bn_bwd_elem(ka, av[j], gv[j], xh, g);
+      ra[j] = ka.a * (g - a1 - xh * a2);
+      bn_bwd_elem(kb, bv[j], gv[j], xh, g);
+      rb[j] = kb.a * (g - b1 - xh * b2);
+      if (forked && i + j < end) { float h, gf_; bn_bwd_elem(kf, bv[j], rb[j], h, gf_); lsf += gf_; lqf = fmaf(gf_, h, lqf); }
+    }
+    if (vec) {
+      *reinterpret_cast<float4*>(oa + i) = make_float4(ra[0], ra[1], ra[2], ra[3]);
+      *reinterpret_cast<float4*>(ob + i) = make_float4(rb[0], rb[1], rb[2], rb[3]);
+    } else {
+      for (int j = 0; j < 4 && i + j < end; ++j) { oa[i + j] = ra[j]; ob[i + j] = rb[j]; }
+    }
+    sf += lsf; qf += lqf;
+  }
+  if (f_partials && f_hi > f_lo) {
+    __shared__ double sh[8];
+    const double SF = block_sum(sf, sh), QF = block_sum(qf, sh + 4);
+    if (threadIdx.x == 0 && forked) {
+      f_partials[((size_t)b * fC + fc) * 2 + 0] = SF;
+      f_partials[((size_t)b * fC + fc) * 2 + 1] = QF;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float slope,
                                                         size_t n, float* __restrict__ dx) {
   const bool vec = (n & 3) == 0;
@@ -733,6 +831,23 @@ extern "C" int dpi_bn_bwd_apply_fork(const float* dy, const float* x, const floa
   bn_bwd_apply_fork_kernel<<<dim3(nb, C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, beta, in_chain, pre_slope, post_slope,
                                                                         partials, nblk, C, V, nb, dx, dgamma, dbeta, fa, fb);
   return dpi_check_launch("bn_bwd_apply_fork");
+}
+
+extern "C" int dpi_bn_bwd_apply_dual(const float* dy, int nblk, int C, size_t V, const float* xa, const float* mi_a, const float* gamma_a,
+                                     const float* beta_a, const float* chain_a, float post_a, const double* partials_a, float* dxa,
+                                     float* dgamma_a, float* dbeta_a, const float* xb, const float* mi_b, const float* gamma_b,
+                                     const float* beta_b, const float* chain_b, float post_b, const double* partials_b, float* dxb,
+                                     float* dgamma_b, float* dbeta_b, int f_lo, int f_hi, const float* f_mi, const float* f_gamma,
+                                     const float* f_beta, float f_post, double* f_partials, void* stream) {
+  DPI_REQUIRE(dy && xa && xb && mi_a && mi_b && partials_a && partials_b && dxa && dxb && C > 0 && V > 0 && nblk > 0,
+              "bn_bwd_apply_dual: bad argument");
+  DPI_REQUIRE(!f_partials || (f_mi && f_lo >= 0 && f_hi <= C && f_lo < f_hi), "bn_bwd_apply_dual: bad fork range");
+  const int nb = dpi_stat_blocks(C, V);
+  const BnSide A{xa, mi_a, gamma_a, beta_a, chain_a, post_a, partials_a, dxa, dgamma_a, dbeta_a};
+  const BnSide B{xb, mi_b, gamma_b, beta_b, chain_b, post_b, partials_b, dxb, dgamma_b, dbeta_b};
+  bn_bwd_apply_dual_kernel<<<dim3(nb, C), 256, 0, (hipStream_t)stream>>>(dy, A, B, nblk, C, V, nb, f_lo, f_hi, f_mi, f_gamma, f_beta, f_post,
+                                                                        f_partials);
+  return dpi_check_launch("bn_bwd_apply_dual");
 }
 
 extern "C" int dpi_chain_add_stats(const float* a, const float* chain_a, const float* b, const float* chain_b, int C, size_t V,

@@ -305,6 +305,34 @@ def _bn_backward_apply(dy, x, mi, gamma, beta, pre_slope, post_slope, red, in_ch
     return dx, dgamma, dbeta
 
 
+def _bn_backward_apply_dual(dy, side_a, side_b, fork=None):
+    """Phase 2 of two BatchNorm backward passes sharing the incoming gradient `dy`, in one kernel.
+    side = (x, mi, gamma, beta, in_chain, post_slope, red) with red = (nblk, partials) from _bn_backward_fork.
+    fork = (c_lo, c_hi, mi_f, gamma_f, beta_f, post_f): additionally take the phase-1 partials of the BatchNorm that dx_b
+    feeds on channels [c_lo, c_hi) (its input being x_b itself).  Returns (dx_a, dgamma_a, dbeta_a), (dx_b, ...), red_f."""
+    L = _lib.load()
+    xa, mia, ga, ea, cha, posta, (nblk, parta) = side_a
+    xb, mib, gb, eb, chb, postb, (nblk_b, partb) = side_b
+    assert nblk == nblk_b
+    C_ = xa.shape[1]
+    V = xa.numel() // C_
+    dxa, dxb = torch.empty_like(xa), torch.empty_like(xb)
+    dga, dea, dgb, deb = (torch.empty_like(g) for g in (ga, ga, gb, gb))
+    red_f = None
+    fargs = [0, 0, None, None, None, 1.0, None]
+    if fork is not None:
+        lo, hi, mif, gf, ef, postf = fork
+        nb = L.dpi_stat_blocks(C_, V)
+        pf = torch.empty(nb * (hi - lo) * 2, dtype=torch.float64, device=xa.device)
+        fargs = [lo, hi, ptr(mif), ptr(gf), ptr(ef), postf, ptr(pf)]
+        red_f = (nb, pf)
+    check(L.dpi_bn_bwd_apply_dual(ptr(dy), nblk, C_, V,
+                                  ptr(xa), ptr(mia), ptr(ga), ptr(ea), ptr(cha), posta, ptr(parta), ptr(dxa), ptr(dga), ptr(dea),
+                                  ptr(xb), ptr(mib), ptr(gb), ptr(eb), ptr(chb), postb, ptr(partb), ptr(dxb), ptr(dgb), ptr(deb),
+                                  *fargs, stream()), "dpi_bn_bwd_apply_dual")
+    return (dxa, dga, dea), (dxb, dgb, deb), red_f
+
+
 def _pre_chain(C_, pre_slope, device):
     return None if pre_slope == 1.0 else slope_chain(C_, pre_slope, device)
 
@@ -486,12 +514,14 @@ class Block3dFn(torch.autograd.Function):
         ch1, ch2 = CH[:c1 * 5], CH[c1 * 5:(c1 + c2) * 5]
         dt, dgB, deB, (redS, redA) = _bn_backward_fork(dy, t, miB, gB, eB, slope, 1.0,
                                                        [(S, miS, gs, es, None, slope), (R, miA, gA, eA, CH, 1.0)])
-        dS, dgs, des = _bn_backward_apply(dt, S, miS, gs, es, 1.0, slope, redS)
-        dcat, dgA, deA = _bn_backward_apply(dt, R, miA, gA, eA, 1.0, 1.0, redA, in_chain=CH)
+        # shortcut-BN and bn1 share dt: one pass; it also takes the phase-1 partials of conv7x7's BatchNorm (its incoming
+        # gradient is bn1's dx on the last channel slice — nothing accumulates into that slice afterwards)
+        (dS, dgs, des), (dcat, dgA, deA), red3 = _bn_backward_apply_dual(
+            dt, (S, miS, gs, es, None, slope, redS), (R, miA, gA, eA, CH, 1.0, redA), fork=(c1 + c2, c1 + c2 + c3, mi3, g3, e3, slope))
         del dt
         dR = torch.empty_like(R)
         # o3 -> o2 -> o1: each conv's backward-data ACCUMULATES into the concat gradient of its input slice
-        _, dg3, de3 = _bn_backward(dcat[:, s3], R[:, s3], mi3, g3, e3, 1.0, slope, dx=dR[:, s3])
+        _, dg3, de3 = _bn_backward_apply(dcat[:, s3], R[:, s3], mi3, g3, e3, 1.0, slope, red3, dx=dR[:, s3])
         dw3 = torch.empty_like(w3)
         conv_bwd_weight_async(d3, R[:, s2], ch2, dR[:, s3], dw3)
         raw_conv_bwd_data(d3, dR[:, s3], w3, dcat[:, s2], accumulate=True)
@@ -561,8 +591,8 @@ class ResPath3dFn(torch.autograd.Function):
         slope = ctx.slope
         dt, dgB, deB, (red3, red1) = _bn_backward_fork(dy, t, miB, gB, eB, slope, 1.0,
                                                        [(r3, mi3, g3, e3, None, slope), (r1, mi1, g1, e1, None, slope)])
-        dr3, dg3, de3 = _bn_backward_apply(dt, r3, mi3, g3, e3, 1.0, slope, red3)
-        dr1, dg1, de1 = _bn_backward_apply(dt, r1, mi1, g1, e1, 1.0, slope, red1)
+        (dr3, dg3, de3), (dr1, dg1, de1), _ = _bn_backward_apply_dual(dt, (r3, mi3, g3, e3, None, slope, red3),
+                                                                     (r1, mi1, g1, e1, None, slope, red1))
         del dt
         dw3, dw1 = torch.empty_like(w3), torch.empty_like(w1)
         conv_bwd_weight_async(d3, x, None, dr3, dw3)
@@ -638,8 +668,8 @@ class SkipJoinFn(torch.autograd.Function):
             raw_upsample2x_bwd(dcat[:, Cs:], Cd, Dd, Hd, Wd, Do, Ho, Wo, linear, ddeep)
         dt, dgB, deB, (red3, red1) = _bn_backward_fork(dcat[:, :Cs], t, miB, gB, eB, slope, 1.0,
                                                        [(r3, mi3, g3, e3, None, slope), (r1, mi1, g1, e1, None, slope)])
-        dr3, dg3, de3 = _bn_backward_apply(dt, r3, mi3, g3, e3, 1.0, slope, red3)
-        dr1, dg1, de1 = _bn_backward_apply(dt, r1, mi1, g1, e1, 1.0, slope, red1)
+        (dr3, dg3, de3), (dr1, dg1, de1), _ = _bn_backward_apply_dual(dt, (r3, mi3, g3, e3, None, slope, red3),
+                                                                     (r1, mi1, g1, e1, None, slope, red1))
         del dt
         dw3, dw1 = torch.empty_like(w3), torch.empty_like(w1)
         conv_bwd_weight_async(d3, x, None, dr3, dw3)

@@ -127,6 +127,16 @@ int dpi_bn_bwd_apply_fork(const float* dy, const float* x, const float* mean_inv
                           const float* beta_a, const float* chain_a, float post_a, double* partials_a,
                           const float* xb, const float* mi_b, const float* gamma_b, const float* beta_b,
                           const float* chain_b, float post_b, double* partials_b, void* stream);
+/* Phase 2 of TWO BatchNorm backward passes that share the incoming gradient dy (the two branches of a residual join), from
+ * their phase-1 partials, in one pass; optionally phase 1 of one more BatchNorm whose incoming gradient is dxb on the
+ * channels [f_lo, f_hi) and whose input is xb itself (raw): f_partials[dpi_stat_blocks][f_hi - f_lo][2]. */
+int dpi_bn_bwd_apply_dual(const float* dy, int nblk, int C, size_t V, const float* xa, const float* mi_a,
+                          const float* gamma_a, const float* beta_a, const float* chain_a, float post_a,
+                          const double* partials_a, float* dxa, float* dgamma_a, float* dbeta_a, const float* xb,
+                          const float* mi_b, const float* gamma_b, const float* beta_b, const float* chain_b,
+                          float post_b, const double* partials_b, float* dxb, float* dgamma_b, float* dbeta_b,
+                          int f_lo, int f_hi, const float* f_mi, const float* f_gamma, const float* f_beta,
+                          float f_post, double* f_partials, void* stream);
 /* t = T_a(a) + T_b(b);  partials[nblk][C][2] = {sum, sum^2} of act(t) with LeakyReLU(slope): the residual join
  * followed by act -> BatchNorm of Block3d / ResPath3d (mulresunet.py:92-94,109-111) in one pass. */
 int dpi_chain_add_stats(const float* a, const float* chain_a, const float* b, const float* chain_b, int C,
