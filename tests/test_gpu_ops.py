@@ -93,7 +93,10 @@ def test_conv_vs_oracle(ops, cin, cout, shape, k, stride):
 
 @pytest.mark.parametrize("cin,cout,shape,k,stride", [(5, 7, (1, 37, 41), 3, 1), (6, 6, (1, 33, 30), 3, 2), (9, 4, (1, 20, 24), 1, 1),
                                                      (9, 12, (1, 33, 30), 3, 2), (13, 17, (1, 70, 45), 3, 1), (16, 8, (1, 9, 12), 3, 1),
-                                                     (10, 10, (1, 64, 64), 3, 2)])
+                                                     (10, 10, (1, 64, 64), 3, 2),
+                                                     # few output channels in 2-D: swapped-orientation backward-weight MFMA path
+                                                     (16, 4, (1, 40, 48), 3, 1), (24, 1, (1, 33, 50), 3, 1), (67, 4, (1, 64, 64), 3, 1),
+                                                     (137, 51, (1, 16, 16), 1, 1), (300, 9, (1, 8, 8), 1, 1)])
 def test_conv2d_vs_oracle(ops, cin, cout, shape, k, stride):
     gen = torch.Generator().manual_seed(7)
     x = torch.randn((1, cin) + shape[1:], generator=gen)
