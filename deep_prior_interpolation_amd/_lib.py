@@ -55,6 +55,8 @@ SIGNATURES = {
     "dpi_bn_bwd_apply_dual": (_I, [_P, _I, _I, _Z] + [_P, _P, _P, _P, _P, _F, _P, _P, _P, _P] * 2 + [_I, _I, _P, _P, _P, _F, _P, _P]),
     "dpi_chain_add_stats": (_I, [_P, _P, _P, _P, _I, _Z, _F, _P, _P, _P]),
     "dpi_lrelu_bwd": (_I, [_P, _P, _F, _Z, _P, _P]),
+    "dpi_act_fwd": (_I, [_P, _Z, _I, _P, _P]),
+    "dpi_act_bwd": (_I, [_P, _P, _Z, _I, _P, _P]),
     "dpi_add": (_I, [_P, _P, _Z, _P, _P]),
     "dpi_channel_sum": (_I, [_P, _I, _Z, _P, _P, _P]),
     "dpi_upsample2x_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),

@@ -24,7 +24,7 @@ def get_activation(act_fun="LeakyReLU"):
     if act_fun == "none":
         return nn.Sequential()
     if act_fun in ("ELU", "Tanh", "Sigmoid"):
-        return hnn.UnsupportedActivation(act_fun)
+        return hnn.Activation(act_fun)
     raise NotImplementedError("unknown activation function %r" % (act_fun,))
 
 

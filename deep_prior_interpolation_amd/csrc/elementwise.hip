@@ -486,6 +486,46 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict_
   }
 }
 
+// ---- the other activations of get_activation (reference base.py:97-114): ELU(alpha = 1), Tanh, Sigmoid --------------------
+// forward y = f(x); backward from the OUTPUT y (what autograd keeps): ELU' = y > 0 ? 1 : y + 1, tanh' = 1 - y^2,
+// sigmoid' = y (1 - y).  (LeakyReLU / ReLU never come here: they are chains fused into their neighbours.)
+__device__ __forceinline__ float act_fwd_one(int kind, float x) {
+  if (kind == DPI_ACT_ELU) return x > 0.f ? x : expm1f(x);
+  if (kind == DPI_ACT_TANH) return tanhf(x);
+  return 1.f / (1.f + expf(-x));
+}
+__device__ __forceinline__ float act_bwd_one(int kind, float y, float dy) {
+  if (kind == DPI_ACT_ELU) return y > 0.f ? dy : dy * (y + 1.f);
+  if (kind == DPI_ACT_TANH) return dy * (1.f - y * y);
+  return dy * (y * (1.f - y));
+}
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, size_t n, int kind, float* __restrict__ y) {
+  const bool vec = (n & 3) == 0;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+    if (vec) {
+      float4 f = *reinterpret_cast<const float4*>(x + i);
+      f.x = act_fwd_one(kind, f.x); f.y = act_fwd_one(kind, f.y); f.z = act_fwd_one(kind, f.z); f.w = act_fwd_one(kind, f.w);
+      *reinterpret_cast<float4*>(y + i) = f;
+    } else {
+      for (int k = 0; k < 4 && i + k < n; ++k) y[i + k] = act_fwd_one(kind, x[i + k]);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, size_t n, int kind,
+                                                      float* __restrict__ dx) {
+  const bool vec = (n & 3) == 0;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+    if (vec) {
+      const float4 f = *reinterpret_cast<const float4*>(y + i);
+      float4 g = *reinterpret_cast<const float4*>(dy + i);
+      g.x = act_bwd_one(kind, f.x, g.x); g.y = act_bwd_one(kind, f.y, g.y); g.z = act_bwd_one(kind, f.z, g.z); g.w = act_bwd_one(kind, f.w, g.w);
+      *reinterpret_cast<float4*>(dx + i) = g;
+    } else {
+      for (int k = 0; k < 4 && i + k < n; ++k) dx[i + k] = act_bwd_one(kind, y[i + k], dy[i + k]);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
                                                   float* __restrict__ y) {
   const bool vec = (n & 3) == 0;
@@ -862,6 +902,18 @@ extern "C" int dpi_lrelu_bwd(const float* dy, const float* x, float slope, size_
   DPI_REQUIRE(dy && x && dx && n > 0, "lrelu_bwd: bad argument");
   lrelu_bwd_kernel<<<ew_blocks(cdivz(n, 4)), 256, 0, (hipStream_t)stream>>>(dy, x, slope, n, dx);
   return dpi_check_launch("lrelu_bwd");
+}
+
+extern "C" int dpi_act_fwd(const float* x, size_t n, int kind, float* y, void* stream) {
+  DPI_REQUIRE(x && y && n > 0 && kind >= DPI_ACT_ELU && kind <= DPI_ACT_SIGMOID, "act_fwd: bad argument");
+  act_fwd_kernel<<<ew_blocks(cdivz(n, 4)), 256, 0, (hipStream_t)stream>>>(x, n, kind, y);
+  return dpi_check_launch("act_fwd");
+}
+
+extern "C" int dpi_act_bwd(const float* dy, const float* y, size_t n, int kind, float* dx, void* stream) {
+  DPI_REQUIRE(dy && y && dx && n > 0 && kind >= DPI_ACT_ELU && kind <= DPI_ACT_SIGMOID, "act_bwd: bad argument");
+  act_bwd_kernel<<<ew_blocks(cdivz(n, 4)), 256, 0, (hipStream_t)stream>>>(dy, y, n, kind, dx);
+  return dpi_check_launch("act_bwd");
 }
 
 extern "C" int dpi_add(const float* a, const float* b, size_t n, float* y, void* stream) {

@@ -103,13 +103,21 @@ class LeakyReLU(nn.Module):
         return "negative_slope=%g" % self.negative_slope
 
 
-class UnsupportedActivation(nn.Module):
+class Activation(nn.Module):
+    """nn.ELU() / nn.Tanh() / nn.Sigmoid() of the reference's get_activation, as stand-alone HIP passes (they are not
+    the default and are not fused into their neighbours like LeakyReLU is)."""
+
     def __init__(self, name):
         super().__init__()
+        if name not in ops.ACT_KINDS:
+            raise NotImplementedError("unknown activation %r" % (name,))
         self.name = name
 
     def forward(self, x):
-        raise NotImplementedError("activation %s has no HIP kernel yet (LeakyReLU / ReLU / none are supported)" % self.name)
+        return ops.activation(x, self.name)
+
+    def extra_repr(self):
+        return self.name
 
 
 class Upsample(nn.Module):

@@ -705,6 +705,30 @@ class LeakyReLUFn(torch.autograd.Function):
         return dx, None
 
 
+ACT_KINDS = {"ELU": 1, "Tanh": 2, "Sigmoid": 3}
+
+
+class ActFn(torch.autograd.Function):
+    """nn.ELU() / nn.Tanh() / nn.Sigmoid() (reference base.py:104-112); the output is what the backward needs."""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        x = _req(x, "activation input")
+        y = torch.empty_like(x)
+        check(_lib.load().dpi_act_fwd(ptr(x), x.numel(), kind, ptr(y), stream()), "dpi_act_fwd")
+        ctx.save_for_backward(y)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _req(dy, "activation grad")
+        dx = torch.empty_like(dy)
+        check(_lib.load().dpi_act_bwd(ptr(dy), ptr(y), dy.numel(), ctx.kind, ptr(dx), stream()), "dpi_act_bwd")
+        return dx, None
+
+
 class AddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -916,6 +940,10 @@ def skip_join(x, deep, rp, slope, mode):
 
 def leaky_relu(x, slope=0.2):
     return LeakyReLUFn.apply(x, float(slope))
+
+
+def activation(x, name):
+    return ActFn.apply(x, ACT_KINDS[name])
 
 
 def add(a, b):

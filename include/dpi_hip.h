@@ -143,6 +143,13 @@ int dpi_chain_add_stats(const float* a, const float* chain_a, const float* b, co
                         size_t V, float slope, float* t, double* partials, void* stream);
 /* dx = dy * act'(x) with act(v) = v>0 ? v : slope*v  (x = the activation INPUT or OUTPUT: same sign) */
 int dpi_lrelu_bwd(const float* dy, const float* x, float slope, size_t n, float* dx, void* stream);
+/* The other activations of the reference's get_activation (architectures/base.py:97-114): ELU (alpha = 1), Tanh, Sigmoid.
+ * Backward takes the activation OUTPUT y. */
+#define DPI_ACT_ELU 1
+#define DPI_ACT_TANH 2
+#define DPI_ACT_SIGMOID 3
+int dpi_act_fwd(const float* x, size_t n, int kind, float* y, void* stream);
+int dpi_act_bwd(const float* dy, const float* y, size_t n, int kind, float* dx, void* stream);
 /* y = a + b */
 int dpi_add(const float* a, const float* b, size_t n, float* y, void* stream);
 /* per-channel sum: out[c] = sum_v x[c][v]   (bias gradients) ; ws: double[dpi_stat_blocks*C*2] */

@@ -267,6 +267,22 @@ def gen_nets():
                                      "--upsample", "nearest"], v25 * 1.0, m25, 3, "2.5d"))
 
 
+def gen_acts():
+    """The non-default activations of get_activation (base.py:97-114) through the reference's own Interpolator:
+    ELU everywhere; Tanh inside + Sigmoid as last activation."""
+    vol = hyperbolic_volume((10, 12, 14), seed=13)
+    msk = trace_mask((10, 12, 14), 0.5, seed=14)
+    base = ["--imgdir", "/nonexistent", "--datadim", "3d", "--filters", "4", "8", "--skip", "4", "--inputdepth", "6",
+            "--upsample", "linear", "--gain", "1"]
+    save("net_mulresunet3d_tiny_elu",
+         run_reference_interpolator(base + ["--activation", "ELU"], (vol * 1.0)[..., None], msk[..., None], 3, "3d elu"))
+    save("net_mulresunet3d_tiny_tanh_sigmoid",
+         run_reference_interpolator(base + ["--activation", "Tanh", "--last_activation", "Sigmoid"],
+                                    (np.abs(vol) * 0.5)[..., None], msk[..., None], 2, "3d tanh/sigmoid"))
+    # (2 iterations only: Tanh saturates behind the BatchNorm weights ~ N(10, 0.2) of init_weights, and from the third
+    #  iteration on the reference's own trajectory depends on summation order at the 1e-2 level)
+
+
 def gen_unet():
     """Reference UNet class (architectures/unet.py) driven directly — its own get_net cannot reach it."""
     import architectures
@@ -480,7 +496,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref_shim.install()
     todo = {"ops": gen_ops, "blocks": gen_blocks, "nets": gen_nets, "structure": gen_structure, "host": gen_host,
-            "unet": gen_unet}
+            "unet": gen_unet, "acts": gen_acts}
     for k, fn in todo.items():
         if a.only is None or k in a.only:
             fn()
