@@ -135,16 +135,23 @@ class Upsample(nn.Module):
 
 
 class Dropout(nn.Module):
-    """Placeholder keeping the reference's module indices; p must be 0 (the reference default)."""
+    """nn.Dropout2d / nn.Dropout3d(p) of the reference (mulresunet.py:24,83,152,227): channel dropout, always in training
+    mode.  p = 0 (the reference default) is the identity; p > 0 draws its mask from torch's device generator — a different
+    random stream than the reference's, like the input noise."""
 
     def __init__(self, p=0.0):
         super().__init__()
         self.p = float(p)
+        if not 0.0 <= self.p < 1.0:
+            raise ValueError("dropout probability must be in [0, 1)")
 
     def forward(self, x):
-        if self.p != 0.0:
-            raise NotImplementedError("dropout > 0 is not on the HIP path")
-        return x
+        if self.p == 0.0:
+            return x
+        return ops.channel_dropout(x, self.p)
+
+    def extra_repr(self):
+        return "p=%g" % self.p
 
 
 class Seq(nn.Sequential):

@@ -729,6 +729,32 @@ class ActFn(torch.autograd.Function):
         return dx, None
 
 
+class ChannelScaleFn(torch.autograd.Function):
+    """y[c] = s[c] * x[c] (channel dropout: s = Bernoulli mask / (1 - p)); linear, so the backward is the same pass on dy."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _req(x, "channel-scale input")
+        C_ = x.shape[1]
+        chain = torch.zeros(C_, 5, dtype=torch.float32, device=x.device)
+        chain[:, 0] = 1.0
+        chain[:, 2] = 1.0
+        chain[:, 3] = scale
+        y = torch.empty_like(x)
+        raw_chain_apply(x, chain, C_, x.numel() // C_, y)
+        ctx.save_for_backward(chain)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (chain,) = ctx.saved_tensors
+        dy = _req(dy, "channel-scale grad")
+        C_ = dy.shape[1]
+        dx = torch.empty_like(dy)
+        raw_chain_apply(dy, chain, C_, dy.numel() // C_, dx)
+        return dx, None
+
+
 class AddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -940,6 +966,13 @@ def skip_join(x, deep, rp, slope, mode):
 
 def leaky_relu(x, slope=0.2):
     return LeakyReLUFn.apply(x, float(slope))
+
+
+def channel_dropout(x, p):
+    """nn.Dropout2d / Dropout3d in training mode (the reference never leaves it): whole channels are zeroed with
+    probability p, the rest scaled by 1/(1-p).  The mask comes from torch's device generator (not the reference's stream)."""
+    keep = (torch.rand(x.shape[1], device=x.device) >= p).to(torch.float32) / (1.0 - p)
+    return ChannelScaleFn.apply(x, keep)
 
 
 def activation(x, name):

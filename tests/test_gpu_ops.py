@@ -372,3 +372,18 @@ def test_conv_bwd_data_accumulate(ops, cin, cout, shape, k, stride):
     acc = base.clone()
     ops.raw_conv_bwd_data(d, dy, w, acc, accumulate=True)
     assert rel(acc, base + plain) < 1e-6
+
+
+def test_channel_dropout_semantics(ops):
+    """Dropout3d(p) in training mode: whole channels zeroed, survivors scaled by 1/(1-p); the gradient sees the same mask."""
+    from deep_prior_interpolation_amd import nn as hnn
+    torch.manual_seed(3)
+    x = torch.randn(1, 64, 5, 6, 7, device=DEV, requires_grad=True)
+    y = hnn.Dropout(0.25)(x)
+    ratio = (y.detach() / x.detach()).amax(dim=(0, 2, 3, 4)), (y.detach() / x.detach()).amin(dim=(0, 2, 3, 4))
+    r = ratio[0].cpu().numpy()
+    assert np.allclose(ratio[0].cpu().numpy(), ratio[1].cpu().numpy(), atol=1e-6)          # one factor per channel
+    assert np.all((np.abs(r) < 1e-6) | (np.abs(r - 1 / 0.75) < 1e-5)) and 0 < (np.abs(r) < 1e-6).sum() < 40
+    y.sum().backward()
+    np.testing.assert_allclose(x.grad[0, :, 0, 0, 0].cpu().numpy(), r, atol=1e-6)
+    assert hnn.Dropout(0.0)(x) is x
