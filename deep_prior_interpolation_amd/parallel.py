@@ -95,6 +95,42 @@ def run_patches(patches, origins, vol_shape, dim, stride, gain, optimise_fn, ran
     return acc.finalize(gain), mine
 
 
+def _run_patches_concurrently(args, patches, origins, vol_shape, pe, T0, conc, rank, world, device, outpath):
+    """This rank's shard, `conc` patches at a time on one GPU (DPI_CONCURRENT_PATCHES=K): every patch of a group gets its own
+    Interpolator, stream and captured iteration graph (main.optimize_concurrently).  Patches whose loop cannot run as a
+    graph (--save_every, data forgetting, >= 2^20 voxels) and flat patches are handled one by one as usual."""
+    from .main import Interpolator, optimize_concurrently
+    cropped = u.in_content_cropped_shape(vol_shape, pe.dim, pe.stride)
+    acc = DeviceOverlapAccumulator(cropped, pe.dim, pe.stride, device)
+    mine = shard_indices(len(patches), rank, world)
+    Ts = [T0] + [Interpolator(args, outpath, device=device, seed=rank * 1000 + k) for k in range(1, conc)]
+    for g0 in range(0, len(mine), conc):
+        group = mine[g0:g0 + conc]
+        live = []
+        for T, i in zip(Ts, group):
+            std = T.load_data(patches[i])
+            if np.isclose(std, 0.0, atol=1e-12):
+                T.out_best, T.elapsed = T.img * T.mask, 0.0
+                T._best_for_acc = torch.from_numpy(np.ascontiguousarray(T.out_best[..., 0], dtype=np.float32))
+                continue
+            T.build_model()
+            T.build_input()
+            if T.graph_capable():
+                live.append(T)
+            else:
+                T.optimize(verbose=False)
+                T._best_for_acc = T._out_best_dev.reshape(T._out_best_dev.shape[2:])
+        optimize_concurrently(live)
+        for T in live:
+            T._best_for_acc = T._out_best_dev.reshape(T._out_best_dev.shape[2:])
+        for T, i in zip(Ts, group):
+            acc.add(T._best_for_acc, origins[i])
+            T.save_result()
+            T.clean()
+    gather_volume(acc)
+    return acc.finalize(args.gain), mine
+
+
 def main(argv=None):
     """Multi-GPU counterpart of main.main(): same flags; each rank optimises its shard, result files are written per
     patch exactly as in the single-process run, rank 0 additionally saves `reconstructed.npy`."""
@@ -138,7 +174,10 @@ def main(argv=None):
         T.clean()
         return best
 
-    if args.datadim == "3d" and vol.ndim == 3:
+    conc = int(os.environ.get("DPI_CONCURRENT_PATCHES", "1"))
+    if args.datadim == "3d" and vol.ndim == 3 and conc > 1:
+        rec, mine = _run_patches_concurrently(args, patches, origins, vol.shape, pe, T, conc, rank, world, device, outpath)
+    elif args.datadim == "3d" and vol.ndim == 3:
         rec, mine = run_patches(patches, origins, vol.shape, pe.dim, pe.stride, args.gain, optimise, rank, world,
                                 DeviceOverlapAccumulator, device)
     else:
