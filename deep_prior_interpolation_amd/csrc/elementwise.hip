@@ -736,15 +736,19 @@ __global__ __launch_bounds__(256) void upsample_lin_bwd_gather_kernel(const floa
 // (8 L1 requests per voxel): 0.95 -> ~0.5 ms for the 51-channel full-resolution tensor.
 __global__ __launch_bounds__(256) void upsample_lin_bwd_axis_kernel(const float* __restrict__ in, float* __restrict__ out, unsigned outer,
                                                                     int n, int no, unsigned inner) {
-  // blockIdx.x walks one [n][inner] slab (32-bit index math only), blockIdx.y strides over the outer slabs
-  const unsigned slab = (unsigned)n * inner, e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= slab) return;
+  // blockIdx.x walks one [n][inner] slab (32-bit index math only), blockIdx.y strides over the outer slabs; a slab shorter
+  // than the workgroup (the W pass: one row) shares it with its neighbours
+  const unsigned slab = (unsigned)n * inner;
+  const unsigned per = slab < 256 ? 256 / slab : 1;
+  const unsigned sub = per > 1 ? threadIdx.x / slab : 0;
+  const unsigned e = per > 1 ? threadIdx.x - sub * slab : blockIdx.x * 256 + threadIdx.x;
+  if (e >= slab || sub >= per) return;
   const unsigned i = e / inner, in_i = e - i * inner;
   int oo[4];
   float wt[4];
   lin_bwd_taps((int)i, n, no, oo, wt);
   const unsigned o0 = oo[0] * inner + in_i, o1 = oo[1] * inner + in_i, o2 = oo[2] * inner + in_i, o3 = oo[3] * inner + in_i;
-  for (unsigned o = blockIdx.y; o < outer; o += gridDim.y) {
+  for (unsigned o = blockIdx.y * per + sub; o < outer; o += gridDim.y * per) {
     const float* __restrict__ p = in + (size_t)o * no * inner;
     out[(size_t)o * slab + e] = (wt[0] * p[o0] + wt[1] * p[o1]) + (wt[2] * p[o2] + wt[3] * p[o3]);
   }
