@@ -135,7 +135,11 @@ __device__ long long g_trace[4][64];
 #else
 #define TR(i)
 #endif
-template <int KD, int NR, int NH, bool FLIP, int S = 1, int WPE = 2, bool PERSIST = false>
+// TAILPACK: a channel count of 4m + 1 (25, 13, 17, 105: the MultiRes widths) leaves ONE channel for the last K = 4 group.
+// Instead of 27 MFMAs per output tile with three zero K-slices, that channel's taps are packed four to an MFMA
+// (K = tap 4g + lk; the staged group holds the channel in all four slots, so lane group lk reads its own slot at its own
+// tap offset): 7 MFMAs per tile, -10.6 % of all MFMAs for Cin = 25.
+template <int KD, int NR, int NH, bool FLIP, int S = 1, int WPE = 2, bool PERSIST = false, bool TAILPACK = false>
 __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
   using G = Geo<KD, NR, NH, S>;
   constexpr int TAPS = KD * 9;
@@ -208,6 +212,38 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
     for (int t = 0; t < TAPS; ++t) wr[t] = ok ? wr[t] : 0.f;
   }
 
+  constexpr int NTG = (TAPS + 3) / 4;                // tap groups of the packed tail
+  const bool tail = TAILPACK && S == 1 && (a.Cin & 3) == 1 && a.Cin > 4;
+  const int cin_main = tail ? a.Cin - 1 : a.Cin;
+  int ttoff[TAILPACK ? NTG : 1];
+  float wt[TAILPACK ? NTG : 1];
+  if constexpr (TAILPACK) {
+#pragma unroll
+    for (int g = 0; g < NTG; ++g) {
+      const int t = 4 * g + lk;
+      const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+      ttoff[g] = t < TAPS ? kd * G::DS + kh * G::RS + kw : 0;
+      wt[g] = 0.f;
+    }
+  }
+  auto load_tail_w = [&]() {                           // raw loads (clamped address), selected in commit_tail_w
+    if constexpr (TAILPACK) {
+      const bool ok = co_w < a.Cout;
+      const float* __restrict__ wp = a.w + (ok ? co_w : 0) * a.w_out_stride + (a.Cin - 1) * a.w_in_stride;
+#pragma unroll
+      for (int g = 0; g < NTG; ++g) {
+        const int t = 4 * g + lk < TAPS ? 4 * g + lk : TAPS - 1;
+        wt[g] = wp[FLIP ? (TAPS - 1 - t) : t];
+      }
+    }
+  };
+  auto commit_tail_w = [&]() {
+    if constexpr (TAILPACK) {
+#pragma unroll
+      for (int g = 0; g < NTG; ++g) wt[g] = (co_w < a.Cout && 4 * g + lk < TAPS) ? wt[g] : 0.f;
+    }
+  };
+
   for (;;) {
     const int vt_next = vt + (int)gridDim.x;
     const bool has_next = PERSIST && vt_next < ntiles;
@@ -231,15 +267,16 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
     }
 
     TR(1);
-    for (int c0 = 0; c0 < a.Cin; c0 += 4) {
+    for (int c0 = 0; c0 < cin_main; c0 += 4) {
       __syncthreads();                                   // everyone is done reading the previous chunk
       TR(2 + (c0 / 4) * 4);
       stage_store<G>(lds, sr, a.chain, a.Cin, c0, goff, loff);
       TR(3 + (c0 / 4) * 4);
       __syncthreads();
       TR(4 + (c0 / 4) * 4);
-      const bool more = c0 + 4 < a.Cin;
-      if (more) stage_load<G>(sr, a.x, a.Cin, V, c0 + 4, goff);   // prefetch the next chunk behind this chunk's MFMAs
+      const bool more = c0 + 4 < cin_main;
+      const bool tail_next = tail && !more;
+      if (more || tail_next) stage_load<G>(sr, a.x, a.Cin, V, c0 + 4, goff);   // prefetch the next group behind this one's MFMAs
       else if (has_next) {                                        // ... or the first chunk of the next tile
         tile_slots<G>(tid, od_n * G::SD - PD, oh_n * S - 1, ow_n * S - 1, a.D, a.H, a.W, goff, loff);
         stage_load<G>(sr, a.x, a.Cin, V, 0, goff);
@@ -255,6 +292,7 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
       };
       load_b(bc, 0);
       const int cn = more ? c0 + 4 : 0;                  // chunk whose weights are fetched next (chunk 0: next tile / harmless)
+      if (tail_next) load_tail_w();
 #pragma unroll
       for (int step = 0; step < G::NSTEP; ++step) {
         const int kd = step / G::NROW, ir = step % G::NROW;
@@ -281,7 +319,32 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
         for (int i = 0; i < G::NB; ++i) bc[i] = bn[i];
         if (ir == G::NROW - 1) commit_w(wr, wn, cn, kd);
       }
+      if (tail_next) commit_tail_w();
       TR(5 + (c0 / 4) * 4);
+    }
+    if constexpr (TAILPACK) {
+      if (tail) {
+        __syncthreads();
+        stage_store<G>(lds, sr, a.chain, a.Cin, cin_main, goff, loff);     // all four slots: channel Cin-1
+        __syncthreads();
+        if (has_next) {
+          tile_slots<G>(tid, od_n * G::SD - PD, oh_n * S - 1, ow_n * S - 1, a.D, a.H, a.W, goff, loff);
+          stage_load<G>(sr, a.x, a.Cin, V, 0, goff);
+        }
+#pragma unroll
+        for (int hr = 0; hr < NR; ++hr) {
+          float tb[NH][NTG];
+#pragma unroll
+          for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int g = 0; g < NTG; ++g) tb[h][g] = lds[lbase + ttoff[g] + hr * G::RS + h * 16];
+#pragma unroll
+          for (int g = 0; g < NTG; ++g)
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+              acc[hr * NH + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[g], tb[h][g], acc[hr * NH + h], 0, 0, 0);
+        }
+      }
     }
     TR(40);
 
@@ -824,8 +887,12 @@ static void launch_variant(const MArgs& a, int nr, int nh, int stride, dim3 grid
     }
     return;
   }
+  const bool tailpack = (a.Cin & 3) == 1 && a.Cin > 4;     // instantiated separately: the packed tail costs ~15 VGPRs
   if (nr == 4) {
-    if constexpr (KD == 3) conv_mfma_kernel<KD, 4, 2, FLIP, 1, 3><<<grid, 256, 0, st>>>(a);
+    if constexpr (KD == 3) {
+      if (tailpack) conv_mfma_kernel<KD, 4, 2, FLIP, 1, 3, false, true><<<grid, 256, 0, st>>>(a);
+      else conv_mfma_kernel<KD, 4, 2, FLIP, 1, 3, false, false><<<grid, 256, 0, st>>>(a);
+    }
     return;
   }
   if (nr == 8) {
@@ -836,7 +903,8 @@ static void launch_variant(const MArgs& a, int nr, int nh, int stride, dim3 grid
     if (a.Cin <= 8) conv_mfma_kernel<KD, 8, 2, FLIP, 1, 3><<<grid, 256, 0, st>>>(a);   // occupancy 3 beats persistence here (measured)
     else {
       if (persist && grid.x > 512) pg.x = 512;        // 2 workgroups per CU (256 VGPRs)
-      conv_mfma_kernel<KD, 8, 2, FLIP, 1, 2, true><<<pg, 256, 0, st>>>(a);
+      if (tailpack) conv_mfma_kernel<KD, 8, 2, FLIP, 1, 2, true, true><<<pg, 256, 0, st>>>(a);
+      else conv_mfma_kernel<KD, 8, 2, FLIP, 1, 2, true, false><<<pg, 256, 0, st>>>(a);
     }
   }
   else if (nh == 2) conv_mfma_kernel<KD, 2, 2, FLIP><<<grid, 256, 0, st>>>(a);
