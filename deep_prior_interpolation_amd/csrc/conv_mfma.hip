@@ -418,9 +418,12 @@ struct BwMArgs {
   // 16-row A operand) is X:  D[ci][(co, t')] = sum_v X[ci][v] dY[co][v + t'] = dW[co][ci][TAPS-1-t'].  With few output
   // channels (64 -> 4: M = 4 of 16 rows the usual way round) this fills the tile: M = 16 input channels, N = 4 co x 27.
   int swap;
+  int y0;                   // first 4-channel group of this launch (blockIdx.y is relative to it)
 };
 
-template <int KD, int S, int NR, int NH>
+// TC != 0: the launch covers a final group that holds only TC real channels (Cin = 4m + 1: TC = 1) and computes just their
+// (channel, tap) column tiles: 2 instead of 7 — the padded channels' 80 columns are not multiplied at all.
+template <int KD, int S, int NR, int NH, int TC = 0>
 __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
 #ifdef DPI_TRACE
   const int trc = (blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 4) ? (int)blockIdx.x : -1;
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
   using G = Geo<KD, NR, NH, S>;
   constexpr int TAPS = KD * 9;
   constexpr int PD = (KD - 1) / 2;
-  constexpr int NQ = 4 * TAPS;                // (channel, tap) columns of this block: 108 (3-D) / 36 (2-D)
+  constexpr int NQ = (TC ? TC : 4) * TAPS;    // (channel, tap) columns of this block: 108 (3-D) / 36 (2-D); tail: TC x TAPS
   constexpr int NTQ = (NQ + 15) / 16;         // MFMA column tiles: 7 (96 % full) / 3 (75 %)
   constexpr int KS = 4 * NH;                  // k-steps (4 voxels each) per output row
   constexpr int LDSF = 4 * G::CS > 4 * NTQ * 256 ? 4 * G::CS : 4 * NTQ * 256;
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
   const int lk = lane >> 4, lj = lane & 15;
   const int wch = lane >> 2, wp = lane & 3;   // dY fetch mapping: channel, float4 piece
   float* __restrict__ dyw = dyl[wid];
-  const int c0 = blockIdx.y * 4, n0 = blockIdx.z * 16;
+  const int c0 = (blockIdx.y + a.y0) * 4, n0 = blockIdx.z * 16;
   const size_t V = (size_t)a.D * a.H * a.W;
   const int Do = (a.D + 2 * PD - KD) / G::SD + 1, Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
   const size_t Vo = (size_t)Do * Ho * Wo;
@@ -969,13 +972,19 @@ int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const f
                                  hipStream_t st) {
   const bool swap = dpi_conv_bwd_weight_mfma_swapped(d, chain);     // the chain can only be applied to the staged tensor
   const MfmaBwPlan p = mfma_bw_plan(d, swap);
-  BwMArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk, 0};
+  BwMArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk, 0, 0};
   dim3 grid(p.nchunks, cdiv(d->Cin, 4), cdiv(d->Cout, 16));
   if (swap) {
     a.x = dy; a.chain = nullptr; a.dy = x; a.Cin = d->Cout; a.Cout = d->Cin; a.swap = 1;
     grid = dim3(p.nchunks, cdiv(d->Cout, 4), cdiv(d->Cin, 16));
   }
-  if (d->stride == 1) {
+  if (d->stride == 1 && d->kd == 3 && (a.Cin & 3) == 1 && a.Cin > 4) {
+    // staged channel count 4m + 1: full groups in one launch, the one-channel group in a second, column-trimmed one
+    dim3 gmain(grid.x, grid.y - 1, grid.z), gtail(grid.x, 1, grid.z);
+    conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<gmain, 256, 0, st>>>(a);
+    a.y0 = (int)grid.y - 1;
+    conv_bwd_weight_mfma_kernel<3, 1, 8, 2, 1><<<gtail, 256, 0, st>>>(a);
+  } else if (d->stride == 1) {
     if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<grid, 256, 0, st>>>(a);
     else conv_bwd_weight_mfma_kernel<1, 1, 8, 2><<<grid, 256, 0, st>>>(a);
   } else if (p.nh == 2) {
