@@ -189,7 +189,7 @@ def main():
             traffic_src = "profiles/r01_traffic_dominant_conv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated)"
         if dom_ms:
             ach = dom_flop / (dom_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<3,8,2> fwd 25->16 k3 @%dx%dx%d" % tuple(a.patch),
+            roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<3,4,2,tail-packed> fwd 25->16 k3 @%dx%dx%d" % tuple(a.patch),
                     "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                     "algorithmic_bytes": 4.0 * (25 + 16) * V, "launch_ms": round(dom_ms, 4), "launches_timed": len(durs), "launch_timing": timing_src,

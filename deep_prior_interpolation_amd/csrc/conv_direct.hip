@@ -448,6 +448,7 @@ int dpi_conv_pw_mfma_run(const dpi_conv_desc* d, const float* x, const float* ch
 int dpi_conv_bwd_data_s2_mfma_run(const dpi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, hipStream_t st);
 void dpi_mfma_variant(const dpi_conv_desc* d, int cout, int* nr, int* nh);
 int dpi_mfma_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth, int* ntw);
+bool dpi_mfma_half_tile(const dpi_conv_desc* d, bool flip);
 static int g_mfma_min_cout = 8;
 extern "C" void dpi_set_mfma_min_cout(int n) { g_mfma_min_cout = n; }
 
@@ -471,6 +472,7 @@ extern "C" int dpi_conv_fwd_stat_blocks(const dpi_conv_desc* d) {
   if (d->k == 3 && d->Cout >= g_mfma_min_cout) {
     int nr, nh, a, b, c;
     dpi_mfma_variant(d, d->Cout, &nr, &nh);
+    if (dpi_mfma_half_tile(d, false)) nr = 4;
     return dpi_mfma_tiles(d, nr, nh, &a, &b, &c);
   }
   if (g_fewco_mfma && dpi_conv_fewco_usable(d)) { int a, b, c; return dpi_conv_fewco_tiles(d, &a, &b, &c); }
