@@ -40,3 +40,11 @@ extern "C" int dpi_device_info(int device, int* cus, int* lds_bytes, size_t* hbm
   }
   return DPI_OK;
 }
+
+__global__ void dpi_marker_kernel() {}
+
+extern "C" int dpi_profile_marker(int id, void* stream) {
+  DPI_REQUIRE(id >= 1 && id < 65536, "profile_marker: id %d out of range", id);
+  dpi_marker_kernel<<<(unsigned)id, 64, 0, (hipStream_t)stream>>>();
+  return dpi_check_launch("profile_marker");
+}

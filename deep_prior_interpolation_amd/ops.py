@@ -80,7 +80,38 @@ def set_timer(t):
     _timer = t
 
 
+# ---- profile tags: DPI_PROFILE_TAGS=<json path> brackets every conv launch with dpi_profile_marker(id) dispatches and writes the
+# id -> layer table at exit, so that tools/rocpd_stats.py can give every layer its own row in a rocprofv3 kernel trace.
+_PROFILE_TAGS = os.environ.get("DPI_PROFILE_TAGS")
+_tag_ids = {}
+
+
+def _tag_id(kind, d):
+    key = "%s %d->%d k%d%s s%d @%dx%dx%d" % (kind, d.Cin, d.Cout, d.k, "" if d.kd > 1 else " (2-D)", d.stride, d.D, d.H, d.W)
+    i = _tag_ids.get(key)
+    if i is None:
+        i = len(_tag_ids) + 2
+        _tag_ids[key] = i
+    return i
+
+
+if _PROFILE_TAGS:
+    import atexit
+    import json
+
+    def _dump_tags():
+        with open(_PROFILE_TAGS, "w") as fp:
+            json.dump({str(i): k for k, i in _tag_ids.items()}, fp, indent=0)
+    atexit.register(_dump_tags)
+
+
 def _timed(kind, d, launch):
+    if _PROFILE_TAGS:
+        L = _lib.load()
+        L.dpi_profile_marker(_tag_id(kind, d), stream())
+        launch()
+        L.dpi_profile_marker(1, stream())
+        return
     if _timer is not None and _timer.match(kind, d):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

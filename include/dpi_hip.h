@@ -46,6 +46,10 @@ const char* dpi_last_error(void);
 int dpi_version(void);
 /* Number of devices / properties as HIP sees them (no torch involved). */
 int dpi_device_info(int device, int* cus, int* lds_bytes, size_t* hbm_bytes, char* name, int name_len);
+/* Profiling aid (no reference counterpart): an empty kernel `dpi_marker_kernel` launched with `id` workgroups of one wave.
+ * rocprofv3's kernel trace records launch grids but not kernel arguments, so tools/rocpd_stats.py uses these markers to
+ * attribute the dispatches that follow (in host launch order) to the layer the caller tagged; id = 1 ends a scope. */
+int dpi_profile_marker(int id, void* stream);
 
 /* ---------------------------------------------------------------- convolution ------------------
  * Replaces nn.Conv3d / nn.Conv2d built at architectures/base.py:123,176 (k in {1,3}, stride in {1,2},

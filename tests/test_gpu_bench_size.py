@@ -1,0 +1,181 @@
+"""configs[1] at FULL size: every convolution of the full-resolution level of the default MulResUnet3D at the bench patch
+256x128x128 (the persistent-workgroup, XCD-tile-order, tail-packed and half-height kernel variants only run at this size).
+
+The CPU oracle cannot convolve 4M voxels x 64 channels in seconds, so parity at this size is
+  (1) crop consistency: conv(x)[box] must equal the fp64 oracle applied to x[box + halo] — boxes at volume corners, faces,
+      tile seams and random interior positions (forward and backward-data);
+  (2) slab decomposition of the weight gradient: dW(full) == sum over depth slabs of dW(slab with halo, dy zeroed on the
+      halo rows), and the first slab against the fp64 oracle;
+  (3) adjoint dot-tests <Ax, y> = <x, A^T y> = <W, dW> and linearity.
+Tolerances: fp32 kernels vs fp64 oracle, norm-wise 5e-6 on crops; identities 1e-5 relative."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dpi_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FULL = (256, 128, 128)
+
+# (Cin, Cout, k, stride): the full-resolution layers of App. A (+ the first stride-2 conv and the first pointwise conv)
+LAYERS = [(25, 16, 3, 1), (64, 4, 3, 1), (67, 4, 3, 1), (25, 1, 3, 1), (4, 8, 3, 1), (8, 13, 3, 1), (25, 25, 3, 2), (64, 25, 1, 1),
+          (25, 16, 1, 1), (67, 25, 1, 1)]
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(b) else np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.linalg.norm((a - b).ravel()) / (np.linalg.norm(b.ravel()) + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from deep_prior_interpolation_amd import ops as _ops
+    return _ops
+
+
+def _boxes(out_shape, rng, n_random=3, size=(6, 6, 20)):
+    """output boxes (start, stop per axis): the 8 corners, seams of the 8x8x32 / 4x4x32 tiles and random interior spots."""
+    D, H, W = out_shape
+    sz = [min(s, n) for s, n in zip(size, out_shape)]
+    starts = [(0, 0, 0), (D - sz[0], H - sz[1], W - sz[2]), (0, H - sz[1], 0), (D - sz[0], 0, W - sz[2]),
+              (D // 2 - 3, H // 2 - 3, W // 2 - 10), (5, 29, W - sz[2]), (D - sz[0], 61, 23)]
+    for _ in range(n_random):
+        starts.append(tuple(int(rng.randint(0, n - s + 1)) for n, s in zip(out_shape, sz)))
+    return [tuple((max(0, min(s0, n - s)), max(0, min(s0, n - s)) + s) for s0, n, s in zip(st, out_shape, sz)) for st in starts]
+
+
+def _oracle_conv_on_crop(x, w, b, box, k, stride, in_shape):
+    """fp64 oracle output on `box` of the OUTPUT: needs input rows [s*o - p, s*(o_end-1) + p] (zero outside the volume)."""
+    p = (k - 1) // 2
+    lo = [stride * b0 - p for b0, _ in box]
+    hi = [stride * (b1 - 1) + p + 1 for _, b1 in box]
+    clo = [max(l, 0) for l in lo]
+    chi = [min(h, n) for h, n in zip(hi, in_shape)]
+    crop = x[:, :, clo[0]:chi[0], clo[1]:chi[1], clo[2]:chi[2]].double().cpu()
+    pad = []
+    for ax in (2, 1, 0):                                       # F.pad order: last axis first
+        pad += [clo[ax] - lo[ax], hi[ax] - chi[ax]]
+    crop = torch.nn.functional.pad(crop, pad)
+    wd = w.double().cpu()
+    y = torch.nn.functional.conv3d(crop, wd, None if b is None else b.double().cpu(), stride=stride, padding=0)
+    return y
+
+
+@pytest.mark.parametrize("cin,cout,k,stride", LAYERS)
+def test_conv_forward_crops_vs_oracle_at_bench_size(ops, cin, cout, k, stride):
+    gen = torch.Generator(device=DEV).manual_seed(cin * 100 + cout)
+    x = torch.randn((1, cin) + FULL, device=DEV, generator=gen)
+    w = torch.randn((cout, cin, k, k, k), device=DEV, generator=gen) / np.sqrt(cin * k ** 3)
+    b = torch.randn(cout, device=DEV, generator=gen)
+    y = ops.conv(x, w, b, stride)
+    out_shape = tuple(y.shape[2:])
+    assert out_shape == tuple(ops.conv_out(n, k, stride) for n in FULL)
+    rng = np.random.RandomState(cin + cout)
+    worst = 0.0
+    for box in _boxes(out_shape, rng):
+        ref = _oracle_conv_on_crop(x, w, b, box, k, stride, FULL)
+        got = y[:, :, box[0][0]:box[0][1], box[1][0]:box[1][1], box[2][0]:box[2][1]]
+        worst = max(worst, rel(got, ref))
+    assert worst < 5e-6, worst
+    # linearity on the whole volume (catches a tile that is skipped or written twice anywhere)
+    x2 = torch.randn((1, cin) + FULL, device=DEV, generator=gen)
+    y2 = ops.conv(x2, w, None, stride)
+    y12 = ops.conv(x + x2, w, b, stride)
+    assert rel(y12, y + y2) < 5e-6
+
+
+@pytest.mark.parametrize("cin,cout,k,stride", LAYERS)
+def test_conv_backward_at_bench_size(ops, cin, cout, k, stride):
+    gen = torch.Generator(device=DEV).manual_seed(cin * 100 + cout + 7)
+    x = torch.randn((1, cin) + FULL, device=DEV, generator=gen).requires_grad_(True)
+    w = (torch.randn((cout, cin, k, k, k), device=DEV, generator=gen) / np.sqrt(cin * k ** 3)).requires_grad_(True)
+    y = ops.conv(x, w, None, stride)
+    dy = torch.randn(y.shape, device=DEV, generator=gen)
+    y.backward(dy)
+    lhs = float((y.detach().double() * dy.double()).sum())
+    assert abs(lhs - float((x.detach().double() * x.grad.double()).sum())) < 1e-5 * abs(lhs) + 1e-2     # <Ax,y> = <x,A^T y>
+    assert abs(lhs - float((w.detach().double() * w.grad.double()).sum())) < 1e-5 * abs(lhs) + 1e-2     # bilinear in W
+    # backward-data on crops: dx = conv_transpose(dy, w); restated through the oracle's autograd on the crop
+    rng = np.random.RandomState(cin * 3 + cout)
+    out_shape = tuple(y.shape[2:])
+    p = (k - 1) // 2
+    worst = 0.0
+    for box in _boxes(FULL, rng, n_random=2, size=(5, 5, 12)):
+        # output rows that touch input box [i0, i1): o in [ceil((i0 - p) / s), floor((i1 - 1 + p) / s)]
+        obox = [(max(0, -((-(i0 - p)) // stride)), min(n, (i1 - 1 + p) // stride + 1)) for (i0, i1), n in zip(box, out_shape)]
+        # input rows those outputs read
+        lo = [stride * o0 - p for o0, _ in obox]
+        hi = [stride * (o1 - 1) + p + 1 for _, o1 in obox]
+        xin = torch.zeros((1, cin) + tuple(h - l for l, h in zip(lo, hi)), dtype=torch.float64, requires_grad=True)
+        yy = torch.nn.functional.conv3d(xin, w.detach().double().cpu(), None, stride=stride)
+        dyc = dy[:, :, obox[0][0]:obox[0][1], obox[1][0]:obox[1][1], obox[2][0]:obox[2][1]].double().cpu()
+        yy.backward(dyc)
+        sl = tuple(slice(i0 - l, i1 - l) for (i0, i1), l in zip(box, lo))
+        ref = xin.grad[(slice(None), slice(None)) + sl]
+        got = x.grad[:, :, box[0][0]:box[0][1], box[1][0]:box[1][1], box[2][0]:box[2][1]]
+        worst = max(worst, rel(got, ref))
+    assert worst < 5e-6, worst
+    # weight gradient: slab decomposition along depth (8 slabs), the first slab against the fp64 oracle
+    if stride == 1:
+        D = FULL[0]
+        nslab = 8
+        step = D // nslab
+        acc = torch.zeros_like(w, dtype=torch.float64)
+        xd = x.detach()
+        for s in range(nslab):
+            d0, d1 = s * step, (s + 1) * step
+            a0, a1 = max(d0 - p, 0), min(d1 + p, D)
+            xs = xd[:, :, a0:a1].contiguous()
+            dys = dy[:, :, a0:a1].clone()
+            dys[:, :, :d0 - a0] = 0
+            if a1 > d1:
+                dys[:, :, -(a1 - d1):] = 0
+            dws = torch.empty_like(w)
+            ops.raw_conv_bwd_weight(ops.make_desc(xs, w, 1), xs, None, dys.contiguous(), dws)
+            acc += dws.double()
+            if s == 0 and cin * cout <= 400:
+                xo = xs.double().cpu().requires_grad_(False)
+                wo = w.detach().double().cpu().requires_grad_(True)
+                O.conv_nd(xo, wo, None, 1).backward(dys.double().cpu())
+                assert rel(dws, wo.grad) < 5e-6
+        assert rel(w.grad, acc) < 5e-6
+
+
+def test_default_net_fused_vs_leaf_at_128x64x64():
+    """Fused autograd nodes vs leaf-by-leaf execution of the DEFAULT 5.9 M-parameter net on a (128,64,64) patch: at this size the
+    full-resolution level runs the same big-tile / persistent kernels as the bench (the leaf path runs them without chains,
+    concat slices or gradient fan-in epilogues)."""
+    import copy
+    from deep_prior_interpolation_amd import ops, utils as u
+    from deep_prior_interpolation_amd.architectures import get_net, mulresunet as M
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    a = parse_arguments(["--imgdir", "x", "--datadim", "3d", "--upsample", "linear"])
+    u.set_seed(0)
+    net = get_net(a, 1)
+    u.init_weights(net, a.inittype, a.initgain)
+    net = net.to(DEV)
+    net2 = copy.deepcopy(net)
+    shape = (128, 64, 64)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    z = 0.1 * torch.randn((1, 64) + shape, device=DEV, generator=gen)
+    img = torch.from_numpy(u.hyperbolic_volume(shape, seed=0) * 40.0)[None, None].to(DEV)
+    mask = torch.from_numpy(u.random_trace_mask(shape, 0.66, seed=1))[None, None].to(DEV)
+    res = []
+    for fused, n in ((True, net), (False, net2)):
+        M.FUSE_BLOCKS = fused
+        try:
+            out = n(z)
+            loss, metrics = ops.masked_loss(out, img, mask, "mae")
+            loss.backward()
+        finally:
+            M.FUSE_BLOCKS = True
+        torch.cuda.synchronize()
+        res.append((out.detach(), float(loss.detach()), {k: p.grad.detach().clone() for k, p in n.named_parameters()}))
+    (o1, l1, g1), (o2, l2, g2) = res
+    assert rel(o1, o2) < 5e-5
+    assert abs(l1 - l2) < 1e-5 * abs(l2)
+    errs = [rel(g1[k], g2[k]) for k in g1 if g1[k].ndim > 1]
+    assert np.median(errs) < 1e-3 and max(errs) < 5e-2, (np.median(errs), max(errs))
