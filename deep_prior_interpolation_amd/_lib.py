@@ -79,6 +79,14 @@ SIGNATURES = {
     "dpi_fill_normal": (_I, [_P, _Z, _F, _F, _U64, _U64, _P]),
     "dpi_fir_axis0": (_I, [_P, _P, _I, _I, _I, _Z, _P, _P]),
     "dpi_axpy": (_I, [_F, _P, _Z, _P, _P]),
+    "dpi_diff_axis": (_I, [_P, _Z, _I, _Z, _I, _F, _I, _P, _P]),
+    "dpi_hale2d": (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _P, _P]),
+    "dpi_structure_tensor": (_I, [_P, _Z, _I, _I, _F, _F, _P, _P, _P, _P]),
+    "dpi_dips": (_I, [_P, _P, _P, _Z, _P, _P, _P]),
+    "dpi_max_ws_floats": (_Z, [_Z]),
+    "dpi_scaled_max": (_I, [_P, _Z, _F, _P, _P, _P]),
+    "dpi_threshold": (_I, [_P, _Z, _P, _P, _P]),
+    "dpi_pocs_project": (_I, [_P, _P, _P, _Z, _P, _P]),
     "dpi_overlap_add": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
     "dpi_overlap_normalize": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
 }

@@ -109,10 +109,14 @@ class ResPath(nn.Module):
             t, b = ops.add(self.conv1x1(x), self.conv3x3(x)), self.bn
         else:
             t, b = ops.add(self.net[0](x), self.net[1](x)), self.net[2]
-        if isinstance(self.act, hnn.LeakyReLU):                 # act -> bn as one chained pass
-            return self.dr(ops.batch_norm(t, b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked, 1.0,
-                                          self.act.negative_slope))
-        return self.dr(b(self.dr(self.act(t))))
+        fuse_act_bn = isinstance(self.act, hnn.LeakyReLU) and (self.nd == 3 or self.dr.p == 0.0)
+        if fuse_act_bn:                                         # act -> bn as one chained pass
+            t = ops.batch_norm(t, b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked, 1.0,
+                               self.act.negative_slope)
+            return self.dr(t) if self.nd == 3 else t            # 3-D: add -> act -> bn -> dropout (mulresunet.py:109-112)
+        if self.nd == 3:
+            return self.dr(b(self.act(t)))
+        return b(self.dr(self.act(t)))                          # 2-D: add -> act -> dropout -> bn (mulresunet.py:59-64)
 
 
 class SkipConcat(Concat):

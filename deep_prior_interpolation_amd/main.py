@@ -51,8 +51,20 @@ class Interpolator:
         self.optimizer = None
         self.noise_seed = int(seed)
         self._noise_step = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._patches_seen = 0          # mixed into the Philox stream id of z: every patch gets its own z (main.py:62-64 draws a fresh one)
 
     # ------------------------------------------------------------------------------------------
+    def begin_patch(self, index, base_seed=0):
+        """Seed everything patch `index` draws — initial weights (torch's CPU generator, consumed by init_weights), z and the
+        per-iteration perturbation (Philox key) — from the patch index alone, so its result does not depend on which process,
+        rank or concurrency slot optimises it.  Patch 0 with base_seed 0 reproduces `u.set_seed(0)` + a fresh Interpolator
+        (bit-identical initial weights to the reference's first patch, tests/test_host.py)."""
+        seed = int(base_seed) + int(index)
+        torch.manual_seed(seed)
+        self.noise_seed = seed
+        self._patches_seen = 0
+        self._noise_step.zero_()
+
     def load_data(self, data):
         """(T,X,Y,C) numpy patch -> (1,C,T,X,Y) fp32 device tensors; returns std of the masked data (main.py:118-139)."""
         self.image_name = data["name"]
@@ -88,8 +100,11 @@ class Interpolator:
             z = u.get_noise((1, a.inputdepth) + self.img.shape[:-1], a.noise_dist).to(self.device) * a.noise_std
         else:
             z = torch.empty((1, a.inputdepth) + self.img.shape[:-1], dtype=torch.float32, device=self.device)
+            # stream id: high word marks "z" (the per-iteration perturbation uses the iteration counter as stream id), low word =
+            # running patch count of this Interpolator, so consecutive patches do not share z
             _lib.check(_lib.load().dpi_fill_normal(_lib.ptr(z), z.numel(), 0.0, float(a.noise_std), self.noise_seed,
-                                                   0xFFFFFFFF, _lib.stream()), "dpi_fill_normal")
+                                                   (0xFFFFFFFF << 32) | (self._patches_seen & 0xFFFFFFFF), _lib.stream()), "dpi_fill_normal")
+        self._patches_seen += 1
         if a.filter_noise_with_wavelet:                         # main.py:66-72
             z = u.ConvolveKernel_1d(kernel=np.load(os.path.join(a.imgdir, "wavelet.npy")), ndim=z.ndim - 2)(z)
         if a.lowpass_fs and a.lowpass_fc:                       # main.py:74-84: 4th-order Butterworth as an FIR along t
@@ -130,9 +145,18 @@ class Interpolator:
             self.input_list.append(u.torch_to_np(input_, True))
         out_ = self.net(input_)
         total_loss, metrics = ops.masked_loss(out_, self.img_, self.mask_, self.loss_kind)
-        total_loss.backward()
-        l, s, p = metrics[:3].tolist()          # one read-back for loss, snr, pcorr
-        self.history.append((l, s, p))
+        reg = self.regularization(out_, total_loss)          # None, or (weight tensor / float, reg loss) of a subclass / add-on
+        if reg is None:
+            total_loss.backward()
+            l, s, p = metrics[:3].tolist()          # one read-back for loss, snr, pcorr
+            self.history.append((l, s, p))
+        else:
+            eps, reg_loss = reg
+            total = total_loss + eps * reg_loss
+            total.backward()
+            main_l, s, p = metrics[:3].tolist()
+            l, r = float(total.item()), float(reg_loss.item())
+            self.history.append((l, main_l, r, s, p))           # HistoryReg layout (main_pocs.py:198-202)
         self.history.lr.append(self.optimizer.param_groups[0]["lr"])
         if self.iiter == 0 or l <= self.loss_min:
             self.loss_min = l
@@ -142,6 +166,34 @@ class Interpolator:
                                  + "_output%s.npy" % str(self.iiter).zfill(self.zfill)), self._to_numpy_out(out_))
         self.iiter += 1
         return l
+
+    def regularization(self, out_, main_loss):
+        """Extra loss term hook.  The base path has none.  With --aa_weight > 0 (2-D / 2.5-D sections) the anti-aliasing add-on
+        is active: aa_weight * loss_fn(Hale2D(dips)(out), 0) — the directional Laplacian of utils/slopes.py along dips estimated
+        once per patch from the Gaussian-smoothed structure tensor of the decimated data (build_regularizer)."""
+        if getattr(self, "_aa_op", None) is None:
+            return None
+        lap = self._aa_op(out_)
+        reg_loss, _ = ops.masked_loss(lap, self._aa_zero, self._aa_one, self.loss_kind)
+        return float(self.args.aa_weight), reg_loss
+
+    def build_regularizer(self):
+        """Anti-aliasing add-on (BASELINE configs[3]; the reference ships the operators — utils/slopes.py, operators/ — but no
+        caller): dips from the structure tensor of the available traces, smoothed with --aa_smooth."""
+        self._aa_op = None
+        a = self.args
+        if not getattr(a, "aa_weight", 0.0):
+            return
+        if self.img_.ndim != 4:
+            raise NotImplementedError("the anti-aliasing add-on works on 2-D / 2.5-D sections (BCHW)")
+        if a.aa_dips is not None:
+            dips = torch.from_numpy(np.load(a.aa_dips).astype(np.float32)).to(self.device).reshape(self.img_.shape)
+        else:
+            dips, _ = u.structure_tensor_dips(self.img_ * self.mask_, smooth=float(a.aa_smooth))
+        self._aa_op = u.Hale2D(dips)
+        self._aa_zero = torch.zeros_like(self.img_)
+        self._aa_one = torch.ones_like(self.img_)
+        self.history = u.HistoryReg(a.epochs)
 
     def optimize(self, net_inputs=None, verbose=True, mode="auto", check_every=64):
         """Adam loop with optional ReduceLROnPlateau and EarlyStopping (main.py:195-220).
@@ -156,7 +208,7 @@ class Interpolator:
         if mode == "auto":
             # big patches are GPU-bound either way and gain from overlapping the weight gradients (eager only);
             # small ones are launch-bound without a graph
-            mode = "eager" if (net_inputs is not None or a.save_every is not None or a.epochs < 3
+            mode = "eager" if (net_inputs is not None or a.save_every is not None or a.epochs < 3 or self.has_regularizer()
                                or a.data_forgetting_factor != 0 or int(np.prod(self.img.shape[:-1])) >= (1 << 20)) else "graph"
         self.optimizer = FusedAdam(self.net.parameters(), lr=a.lr)
         ops.set_weight_grad_overlap(mode == "eager" and int(np.prod(self.img.shape[:-1])) >= (1 << 20))
@@ -246,10 +298,13 @@ class Interpolator:
                     print("Iter %d, Loss = %+.2e, SNR = %+2.2f dB, PCORR = %+.2f %%" % (n, l, s_, p_ * 100), "\r", end="")
         self.graph_finish()
 
+    def has_regularizer(self):
+        return getattr(self, "_aa_op", None) is not None
+
     def graph_capable(self):
         """True when optimize(mode='auto') would take the hipGraph path for the loaded patch."""
         a = self.args
-        return not (a.save_every is not None or a.epochs < 3 or a.data_forgetting_factor != 0
+        return not (a.save_every is not None or a.epochs < 3 or a.data_forgetting_factor != 0 or self.has_regularizer()
                     or int(np.prod(self.img.shape[:-1])) >= (1 << 20))
 
     # ------------------------------------------------------------------------------------------
@@ -266,7 +321,10 @@ class Interpolator:
         self.iiter = 0
         self.loss_min = None
         self._out_best_dev = None
-        self.history = u.History(self.args.epochs)
+        self.history = self._new_history()
+
+    def _new_history(self):
+        return u.HistoryReg(self.args.epochs) if self.has_regularizer() else u.History(self.args.epochs)
 
 
 def optimize_concurrently(Ts, check_every=64):
@@ -280,6 +338,7 @@ def optimize_concurrently(Ts, check_every=64):
     streams = [torch.cuda.Stream(device=T.device) for T in Ts]
     graphs = []
     for T, st in zip(Ts, streams):
+        st.wait_stream(torch.cuda.current_stream(T.device))      # z / data / weights were produced on the caller's stream
         with torch.cuda.stream(st):
             T.optimizer = None
             graphs.append(T.graph_prepare())
@@ -290,11 +349,18 @@ def optimize_concurrently(Ts, check_every=64):
                 with torch.cuda.stream(st):
                     g.replay()
         if j % check_every == 0:
-            alive = [bool(al and int(T.optimizer.active.item()) != 0) for al, T in zip(alive, Ts)]
+            # poll every patch on ITS stream: the read-back waits for the replays queued so far, so the host never runs more than
+            # check_every replays ahead of the device and stops replaying a patch whose loop ended on the device (early stop / NaN)
+            for k, (T, st) in enumerate(zip(Ts, streams)):
+                if alive[k]:
+                    with torch.cuda.stream(st):
+                        alive[k] = int(T.optimizer.active.item()) != 0
             if not any(alive):
                 break
-    for T in Ts:
-        T.graph_finish()
+    for T, st in zip(Ts, streams):
+        with torch.cuda.stream(st):
+            T.graph_finish()
+        torch.cuda.current_stream(T.device).wait_stream(st)      # consumers (overlap-add, save_result) run on the caller's stream
         T.elapsed = time() - start
 
 
@@ -317,9 +383,11 @@ def main(argv=None):
             T.out_best = T.img * T.mask
             T.elapsed = 0.0
         else:
+            T.begin_patch(i)
             if T.net is None or not args.start_from_prev:
                 T.build_model(netpath=args.netdir[i]) if len(args.netdir) != 0 else T.build_model()
             T.build_input()
+            T.build_regularizer()
             T.optimize()
         T.save_result()
         T.clean()

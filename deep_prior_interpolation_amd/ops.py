@@ -87,7 +87,7 @@ _tag_ids = {}
 
 
 def _tag_id(kind, d):
-    key = "%s %d->%d k%d%s s%d @%dx%dx%d" % (kind, d.Cin, d.Cout, d.k, "" if d.kd > 1 else " (2-D)", d.stride, d.D, d.H, d.W)
+    key = "%s %d->%d k%d%s s%d @%dx%dx%d" % (kind, d.Cin, d.Cout, d.k, " (2-D)" if d.D == 1 else "", d.stride, d.D, d.H, d.W)
     i = _tag_ids.get(key)
     if i is None:
         i = len(_tag_ids) + 2

@@ -37,6 +37,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._table_host = torch.empty(len(ps) * 4, dtype=torch.int64).pin_memory()
         self._table = torch.empty(len(ps) * 4, dtype=torch.int64, device=dev)
         self._table_key = None
+        self._table_copied = None       # event recorded after the last async H2D copy out of _table_host
 
     def set_lr(self, lr):
         self.param_groups[0]["lr"] = lr
@@ -54,8 +55,16 @@ class FusedAdam(torch.optim.Optimizer):
             if not g.is_contiguous():
                 raise _lib.DpiError("FusedAdam.step: non-contiguous gradient")
             rows += [p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()]
+        if torch.cuda.is_current_stream_capturing():
+            # an H2D copy node would re-read the pinned staging buffer on every replay — after later eager steps rewrote it.
+            # Callers run one eager iteration first (Interpolator.graph_prepare), so the table is normally current here.
+            raise _lib.DpiError("FusedAdam.step: gradient buffers changed inside a graph capture; run one eager step first")
+        if self._table_copied is not None:
+            self._table_copied.synchronize()         # the previous async copy must have left the pinned buffer
         self._table_host.copy_(torch.tensor(rows, dtype=torch.int64))
         self._table.copy_(self._table_host, non_blocking=True)
+        self._table_copied = torch.cuda.Event()
+        self._table_copied.record()
         self._table_key = key
 
     @torch.no_grad()

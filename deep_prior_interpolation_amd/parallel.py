@@ -1,7 +1,10 @@
 """Patch-parallel execution across the GPUs of one node.
 
-Patches are independent optimisations (reference main.py:274-295 iterates them sequentially), so rank r of W
-takes patch indices {p : p mod W == r}; there is NO collective inside the hot path.  The only exchange is the
+Patches are independent optimisations (reference main.py:274-295 iterates them sequentially), so ranks pull patch
+indices from a shared counter (PatchQueue: an atomic fetch-add on torch.distributed's store — no data-path collective;
+skipped or early-stopped patches therefore never idle a rank; DPI_STATIC_SHARD=1 restores the static p mod W split).
+Every patch seeds its own weights / z / noise stream from its index (Interpolator.begin_patch), so a patch's result does
+not depend on the rank, the world size or the schedule.  The only exchange is the
 final reassembly (reference data.reconstruct_patches, data.py:87-130): every rank overlap-adds its best outputs
 into a local full-volume accumulator and ONE all-reduce(sum) of that fp32 volume (RCCL over xGMI; gloo in the
 CPU tests) followed by the analytic hit-count normalisation gives every rank the reconstructed volume.
@@ -18,12 +21,49 @@ import torch.distributed as dist
 from . import _lib
 from . import utils as u
 
-__all__ = ["shard_indices", "DeviceOverlapAccumulator", "HostOverlapAccumulator", "gather_volume", "run_patches", "main"]
+__all__ = ["shard_indices", "PatchQueue", "DeviceOverlapAccumulator", "HostOverlapAccumulator", "gather_volume", "run_patches",
+           "optimise_volume", "main"]
 
 
 def shard_indices(num_patches, rank, world):
     """Round-robin ownership: equal-cost patches => at most one patch of imbalance (343 patches / 8 = 43,43,...,42)."""
     return list(range(rank, num_patches, world))
+
+
+class PatchQueue:
+    """Work queue over patch indices 0..num-1 shared by all ranks.
+
+    claim(n) hands out the next n indices (fewer at the end, [] when exhausted).  With a process group the counter lives
+    in the c10d store (`store.add` is an atomic fetch-add served by rank 0's TCPStore — control plane only, a few bytes
+    per patch); without one it is a local counter.  static=(rank, world) gives the round-robin split instead."""
+
+    def __init__(self, num, store=None, key="dpi/next_patch", static=None):
+        self.num, self.store, self.key = int(num), store, key
+        self._local = 0
+        self._static = None if static is None else shard_indices(self.num, *static)
+
+    @classmethod
+    def for_process_group(cls, num, key="dpi/next_patch"):
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if os.environ.get("DPI_STATIC_SHARD", "0") == "1":
+            return cls(num, static=(rank, world))
+        if world > 1:
+            from torch.distributed import distributed_c10d
+            return cls(num, store=distributed_c10d._get_default_store(), key=key)
+        return cls(num)
+
+    def claim(self, n=1):
+        n = int(n)
+        if self._static is not None:
+            out, self._static = self._static[:n], self._static[n:]
+            return out
+        if self.store is not None:
+            end = int(self.store.add(self.key, n))
+        else:
+            self._local += n
+            end = self._local
+        return [i for i in range(end - n, end) if i < self.num]
 
 
 class HostOverlapAccumulator:
@@ -82,30 +122,46 @@ def gather_volume(acc):
 
 
 def run_patches(patches, origins, vol_shape, dim, stride, gain, optimise_fn, rank=0, world=1, accumulator_cls=None,
-                device="cpu"):
-    """Optimise this rank's shard with `optimise_fn(index, patch) -> best output (patch-shaped)`, overlap-add locally,
-    all-reduce once, normalise.  Returns (reconstructed volume of the cropped shape, indices this rank processed)."""
+                device="cpu", queue=None):
+    """Optimise this rank's share with `optimise_fn(index, patch) -> best output (patch-shaped)`, overlap-add locally,
+    all-reduce once, normalise.  `queue` (PatchQueue) hands out the indices; None = static round-robin shard.
+    Returns (reconstructed volume of the cropped shape, indices this rank processed)."""
     accumulator_cls = accumulator_cls or HostOverlapAccumulator
     cropped = u.in_content_cropped_shape(vol_shape, dim, stride)
     acc = accumulator_cls(cropped, dim, stride, device)
-    mine = shard_indices(len(patches), rank, world)
-    for i in mine:
+    queue = queue or PatchQueue(len(patches), static=(rank, world))
+    mine = []
+    while True:
+        got = queue.claim(1)
+        if not got:
+            break
+        i = got[0]
         acc.add(optimise_fn(i, patches[i]), origins[i])
+        mine.append(i)
     gather_volume(acc)
     return acc.finalize(gain), mine
 
 
-def _run_patches_concurrently(args, patches, origins, vol_shape, pe, T0, conc, rank, world, device, outpath):
-    """This rank's shard, `conc` patches at a time on one GPU (DPI_CONCURRENT_PATCHES=K): every patch of a group gets its own
-    Interpolator, stream and captured iteration graph (main.optimize_concurrently).  Patches whose loop cannot run as a
-    graph (--save_every, data forgetting, >= 2^20 voxels) and flat patches are handled one by one as usual."""
+def optimise_volume(args, patches, origins, vol_shape, pe, device, outpath=None, conc=1, queue=None, save=True, timings=None):
+    """Deep-prior optimisation of every patch this rank pulls from `queue`, `conc` patches at a time on one GPU, overlap-added
+    into a device accumulator; ONE all-reduce at the end; returns (reconstructed volume, indices processed here).
+
+    conc > 1 (DPI_CONCURRENT_PATCHES): every patch of a group gets its own Interpolator, stream and captured iteration graph
+    (main.optimize_concurrently).  Patches whose loop cannot run as a graph (--save_every, data forgetting, >= 2^20 voxels)
+    and flat patches are handled one by one.  save=False skips the per-patch result files (bench.py)."""
+    from time import perf_counter
     from .main import Interpolator, optimize_concurrently
     cropped = u.in_content_cropped_shape(vol_shape, pe.dim, pe.stride)
     acc = DeviceOverlapAccumulator(cropped, pe.dim, pe.stride, device)
-    mine = shard_indices(len(patches), rank, world)
-    Ts = [T0] + [Interpolator(args, outpath, device=device, seed=rank * 1000 + k) for k in range(1, conc)]
-    for g0 in range(0, len(mine), conc):
-        group = mine[g0:g0 + conc]
+    queue = queue or PatchQueue.for_process_group(len(patches))
+    Ts = [Interpolator(args, outpath, device=device) for _ in range(max(conc, 1))]
+    mine = []
+    t_setup = t_loop = 0.0
+    while True:
+        group = queue.claim(len(Ts))
+        if not group:
+            break
+        t0 = perf_counter()
         live = []
         for T, i in zip(Ts, group):
             std = T.load_data(patches[i])
@@ -113,27 +169,38 @@ def _run_patches_concurrently(args, patches, origins, vol_shape, pe, T0, conc, r
                 T.out_best, T.elapsed = T.img * T.mask, 0.0
                 T._best_for_acc = torch.from_numpy(np.ascontiguousarray(T.out_best[..., 0], dtype=np.float32))
                 continue
-            T.build_model()
+            T.begin_patch(i)
+            if T.net is None or not args.start_from_prev:
+                T.build_model()
             T.build_input()
-            if T.graph_capable():
+            T.build_regularizer()
+            if len(Ts) > 1 and T.graph_capable():
                 live.append(T)
             else:
                 T.optimize(verbose=False)
                 T._best_for_acc = T._out_best_dev.reshape(T._out_best_dev.shape[2:])
+        t1 = perf_counter()
         optimize_concurrently(live)
         for T in live:
             T._best_for_acc = T._out_best_dev.reshape(T._out_best_dev.shape[2:])
         for T, i in zip(Ts, group):
             acc.add(T._best_for_acc, origins[i])
-            T.save_result()
+            if save:
+                T.save_result()
             T.clean()
+            mine.append(i)
+        t_setup += t1 - t0
+        t_loop += perf_counter() - t1
     gather_volume(acc)
-    return acc.finalize(args.gain), mine
+    rec = acc.finalize(args.gain)
+    if timings is not None:
+        timings.update(setup_s=t_setup, loop_s=t_loop)
+    return rec, mine
 
 
 def main(argv=None):
-    """Multi-GPU counterpart of main.main(): same flags; each rank optimises its shard, result files are written per
-    patch exactly as in the single-process run, rank 0 additionally saves `reconstructed.npy`."""
+    """Multi-GPU counterpart of main.main(): same flags; each rank optimises the patches it pulls from the shared queue, result
+    files are written per patch exactly as in the single-process run, rank 0 additionally saves `reconstructed.npy`."""
     from .data import extract_patches, patch_extractor_for
     from .main import Interpolator
     from .parameter import parse_arguments
@@ -147,7 +214,8 @@ def main(argv=None):
     if world > 1:
         dist.init_process_group("nccl", device_id=device)       # "nccl" is RCCL on ROCm
     u.set_seed(0)
-    outpath = os.path.join("./results/", args.outdir if args.outdir is not None else "run")
+    args.outdir = args.outdir or "run"       # reconstruct_patches(args) joins it too
+    outpath = os.path.join("./results/", args.outdir)
     if rank == 0:
         os.makedirs(outpath, exist_ok=True)
         u.write_args(os.path.join(outpath, "args.txt"), args)
@@ -157,35 +225,35 @@ def main(argv=None):
     vol = np.load(os.path.join(args.imgdir, args.imgname), allow_pickle=True)
     pe = patch_extractor_for(vol.shape, args.patch_shape, args.patch_stride, args.datadim, args.imgchannel)
     origins = u.window_origins(vol.shape, pe.dim, pe.stride)
-    T = Interpolator(args, outpath, device=device, seed=rank)
-
-    def optimise(i, patch):
-        std = T.load_data(patch)
-        if np.isclose(std, 0.0, atol=1e-12):
-            T.out_best, T.elapsed = T.img * T.mask, 0.0
-            best = torch.from_numpy(np.ascontiguousarray(T.out_best[..., 0], dtype=np.float32))
-        else:
-            if T.net is None or not args.start_from_prev:
-                T.build_model()
-            T.build_input()
-            T.optimize(verbose=False)
-            best = T._out_best_dev.reshape(T._out_best_dev.shape[2:]) if args.datadim == "3d" else torch.from_numpy(T.out_best)
-        T.save_result()
-        T.clean()
-        return best
-
     conc = int(os.environ.get("DPI_CONCURRENT_PATCHES", "1"))
-    if args.datadim == "3d" and vol.ndim == 3 and conc > 1:
-        rec, mine = _run_patches_concurrently(args, patches, origins, vol.shape, pe, T, conc, rank, world, device, outpath)
-    elif args.datadim == "3d" and vol.ndim == 3:
-        rec, mine = run_patches(patches, origins, vol.shape, pe.dim, pe.stride, args.gain, optimise, rank, world,
-                                DeviceOverlapAccumulator, device)
+    queue = PatchQueue.for_process_group(len(patches))
+    if args.datadim == "3d" and vol.ndim == 3:
+        if (args.imgchannel or 1) != 1:
+            raise _lib.DpiError("the device overlap-add path re-assembles single-channel 3-D volumes (imgchannel = 1)")
+        rec, mine = optimise_volume(args, patches, origins, vol.shape, pe, device, outpath, conc, queue)
     else:
         # 2-D / 2.5-D slabs: result files only; rank 0 re-assembles them on the host like the reference does
         from .data import reconstruct_patches
-        mine = shard_indices(len(patches), rank, world)
-        for i in mine:
-            optimise(i, patches[i])
+        T = Interpolator(args, outpath, device=device)
+        mine = []
+        while True:
+            got = queue.claim(1)
+            if not got:
+                break
+            i = got[0]
+            std = T.load_data(patches[i])
+            if np.isclose(std, 0.0, atol=1e-12):
+                T.out_best, T.elapsed = T.img * T.mask, 0.0
+            else:
+                T.begin_patch(i)
+                if T.net is None or not args.start_from_prev:
+                    T.build_model()
+                T.build_input()
+                T.build_regularizer()
+                T.optimize(verbose=False)
+            T.save_result()
+            T.clean()
+            mine.append(i)
         if world > 1:
             dist.barrier()
         rec = reconstruct_patches(args) if rank == 0 else None

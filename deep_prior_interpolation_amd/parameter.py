@@ -72,7 +72,11 @@ _FLAGS = [
     (("--reduce_lr",), dict(action="store_true", default=False, help="Use ReduceLROnPlateau scheduler")),
     (("--earlystop_patience",), dict(type=int, required=False, help="Early stopping patience")),
     (("--earlystop_min_delta",), dict(type=float, required=False, default=1.0, help="Early stopping min percentage delta")),
-    # POCS (parsed for args.txt compatibility; the POCS variant itself is out of scope)
+    # anti-aliasing add-on (ours: the reference ships operators/ + utils/slopes.py without a caller)
+    (("--aa_weight",), dict(type=float, required=False, default=0.0, help="Weight of the directional-Laplacian regulariser (0 = off)")),
+    (("--aa_smooth",), dict(type=float, required=False, default=2.0, help="Gaussian smoothing (std, samples) of the structure tensor")),
+    (("--aa_dips",), dict(type=str, required=False, help="Optional .npy with a precomputed dip field (same shape as a section)")),
+    # POCS regulariser (main_pocs.py)
     (("--pocs_alpha",), dict(type=float, required=False, default=0.1, help="POCS data weighting.")),
     (("--pocs_thresh",), dict(type=float, required=False, default=5.0, help="POCS thresholding percentage")),
     (("--pocs_weight",), dict(type=float, required=False, help="POCS regularization weight")),

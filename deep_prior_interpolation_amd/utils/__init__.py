@@ -6,3 +6,5 @@ from .processing import *       # noqa: F401,F403
 from .patch_extractor import *  # noqa: F401,F403
 from .mask import *             # noqa: F401,F403
 from .synthetic import *        # noqa: F401,F403
+from .slopes import *          # noqa: F401,F403
+from .pocs import *            # noqa: F401,F403

@@ -7,7 +7,7 @@ import torch
 
 from .generic import ten_digit
 
-__all__ = ["snr", "pcorr", "History"]
+__all__ = ["snr", "pcorr", "History", "HistoryReg"]
 
 
 def _lib(output, target):
@@ -57,5 +57,40 @@ class History:
 
     def __str__(self):
         return "Loss : %s\nSNR  : %s\nPCORR: %s" % (self.loss, self.snr, self.pcorr)
+
+    __repr__ = __str__
+
+
+class HistoryReg:
+    """History with the data-fidelity and regularisation terms split (reference utils/metrics.py:88-137; main_pocs.py:35)."""
+
+    def __init__(self, epochs):
+        self.loss, self.snr, self.pcorr, self.lr, self.df, self.reg = [], [], [], [], [], []
+        self.msg = "Iter %s, Loss = %+.2e, DF = %.2e, REG = %.2e, SNR = %+.2f dB, PCORR = %+.2f %%"
+        self.zfill = ten_digit(epochs)
+
+    def __getitem__(self, i):
+        return self.loss[i], self.reg[i], self.snr[i], self.pcorr[i]
+
+    def __setitem__(self, i, values):
+        self.loss[i], self.df[i], self.reg[i], self.snr[i], self.pcorr[i] = values
+
+    def append(self, values):
+        l, d, r, s, p = values
+        self.loss.append(l)
+        self.df.append(d)
+        self.reg.append(r)
+        self.snr.append(s)
+        self.pcorr.append(p)
+
+    def __len__(self):
+        assert len(self.loss) == len(self.snr) == len(self.pcorr) == len(self.lr) == len(self.df) == len(self.reg)
+        return len(self.loss)
+
+    def log_message(self, idx):
+        return self.msg % (str(idx + 1).zfill(self.zfill), self.loss[idx], self.df[idx], self.reg[idx], self.snr[idx], self.pcorr[idx] * 100)
+
+    def __str__(self):
+        return "Loss : %s\nReg  : %s\nSNR  : %s\nPCORR: %s" % (self.loss, self.reg, self.snr, self.pcorr)
 
     __repr__ = __str__

@@ -251,6 +251,34 @@ int dpi_overlap_add(const float* patch, int pd, int ph, int pw, int od, int oh, 
 int dpi_overlap_normalize(float* acc, int D, int H, int W, int pd, int ph, int pw, int sd, int sh,
                           int sw, float gain, void* stream);
 
+/* ---------------------------------------------------------------- anti-aliasing operators -------
+ * Linear operators of the anti-aliasing add-on (BASELINE configs[3]); `adjoint` != 0 applies the exact transpose, which is
+ * what the backward of a loss term built on the operator needs (reference operators/base.py:53-67 `dottest` is the unit test).
+ *
+ * dpi_diff_axis replaces utils/processing.py:139-181 first_derivative (stencil 0 forward, 1 backward, 2 centered) and
+ * second_derivative (stencil 3) along the middle axis of a contiguous [outer][n][inner] view, and with stencil 0, spacing 1 on the
+ * H axis of BCHW it is operators/derivative.py:8-21 VerticalGrad.forward / .adjoint.   x != y. */
+int dpi_diff_axis(const float* x, size_t outer, int n, size_t inner, int stencil, float spacing, int adjoint, float* y,
+                  void* stream);
+/* Replaces utils/slopes.py:51-105 directional_laplacian / Hale2D.forward on [N][H][W] planes with coefficient planes
+ * a = cos^2, b = -cos sin, c = sin^2 of the dips (same shape as x):  y = -(Dh(a Dv x + b Dh x) + Dv(b Dv x + c Dh x)). */
+int dpi_hale2d(const float* x, const float* a, const float* b, const float* c, size_t N, int H, int W, int adjoint, float* y,
+               void* stream);
+/* Replaces utils/slopes.py:19-22 (forward-difference gradients and their products) and :35-46 (eigen-analysis: dip angle phi
+ * with NaN -> 0, anisotropy 1 - l2/l1); the Gaussian smoothing in between (:25-32) is dpi_fir_axis0 along H and W. */
+int dpi_structure_tensor(const float* x, size_t N, int H, int W, float dv, float dh, float* gvv, float* gvh, float* ghh,
+                         void* stream);
+int dpi_dips(const float* gvv, const float* gvh, const float* ghh, size_t n, float* phi, float* anisotropy, void* stream);
+
+/* ---------------------------------------------------------------- POCS regulariser --------------
+ * Replaces utils/pocs.py:5-19 (threshold / compute_threshold: out = max(x) * scale with scale = perc/100, kept on the device;
+ * y = x * ((x > th) + (x < -th)) on the real view of the spectrum) and :80-84 (y = weighted_data + weighted_mask * x).
+ * The transform between them (reference: torch.rfft / irfft, main_pocs.py:156-157) is the rocFFT library call. */
+size_t dpi_max_ws_floats(size_t n);
+int dpi_scaled_max(const float* x, size_t n, float scale, float* ws, float* out, void* stream);
+int dpi_threshold(const float* x, size_t n, const float* thresh, float* y, void* stream);
+int dpi_pocs_project(const float* x, const float* wdata, const float* wmask, size_t n, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -542,3 +542,123 @@ def reconstruct_nd(patch_array, dim, stride):
 def nan_to_binary_mask(a):
     """utils/processing.py:27-31 bool2bin(logic=True): finite -> 1, NaN -> 0."""
     return np.where(np.isnan(a), 0.0, 1.0).astype(a.dtype)
+
+
+# ------------------------------------------------------------------------------------------
+# Anti-aliasing add-on operators and POCS (SURVEY §8f rows 3-4), numpy float64 restatements
+# ------------------------------------------------------------------------------------------
+def first_derivative_np(x, spacing=1.0, axis=0, stencil="forward"):
+    """reference utils/processing.py:139-162."""
+    x = np.moveaxis(np.asarray(x), axis, 0)
+    g = np.zeros_like(x)
+    if stencil == "centered":
+        g[1:-1] = (0.5 * x[2:] - 0.5 * x[:-2]) / spacing
+    elif stencil == "forward":
+        g[:-1] = (x[1:] - x[:-1]) / spacing
+    elif stencil == "backward":
+        g[1:] = (x[1:] - x[:-1]) / spacing
+    else:
+        raise ValueError(stencil)
+    return np.moveaxis(g, 0, axis)
+
+
+def second_derivative_np(x, spacing=1.0, axis=0):
+    """reference utils/processing.py:165-181."""
+    x = np.moveaxis(np.asarray(x), axis, 0)
+    g = np.zeros_like(x)
+    g[1:-1] = (x[2:] - 2 * x[1:-1] + x[:-2]) / spacing ** 2
+    return np.moveaxis(g, 0, axis)
+
+
+def vertical_grad_np(x, adjoint=False):
+    """reference operators/derivative.py:8-21 (BCHW, difference along H)."""
+    x = np.asarray(x)
+    y = np.zeros_like(x)
+    if not adjoint:
+        y[:, :, :-1] = x[:, :, 1:] - x[:, :, :-1]
+    else:
+        y[:, :, :-1] -= x[:, :, :-1]
+        y[:, :, 1:] += x[:, :, :-1]
+    return y
+
+
+def hale2d_np(x, theta):
+    """reference utils/slopes.py:51-69 / 72-105: -(Dh(a Dv x + b Dh x) + Dv(b Dv x + c Dh x)), forward differences."""
+    u1, u2 = np.cos(theta), -np.sin(theta)
+    gv = first_derivative_np(x, axis=2)
+    gh = first_derivative_np(x, axis=3)
+    p1 = u1 * u1 * gv + u1 * u2 * gh
+    p2 = u1 * u2 * gv + u2 * u2 * gh
+    return -(first_derivative_np(p1, axis=3) + first_derivative_np(p2, axis=2))
+
+
+def linear_operator_matrix(fn, shape):
+    """Dense matrix of a linear map on tensors of `shape` (tiny shapes only): column k = fn(e_k).  Used to check adjoint
+    kernels against the TRANSPOSE of the forward operator."""
+    n = int(np.prod(shape))
+    cols = []
+    for k in range(n):
+        e = np.zeros(n)
+        e[k] = 1.0
+        cols.append(np.asarray(fn(e.reshape(shape))).reshape(-1))
+    return np.stack(cols, axis=1)
+
+
+def gaussian_kernel_np(M, std):
+    n = np.arange(0, M) - (M - 1.0) / 2.0
+    return np.exp(-n ** 2 / (2 * std * std))
+
+
+def conv_same_axis_np(x, taps, axis):
+    """y[i] = sum_k taps[k] x[i + K//2 - k], zero padded (the ConvTransposeNd with padding K//2 of utils/processing.py:122-130)."""
+    x = np.moveaxis(np.asarray(x, dtype=np.float64), axis, -1)
+    K = len(taps)
+    p = K // 2
+    xp = np.pad(x, [(0, 0)] * (x.ndim - 1) + [(p, p)])
+    y = np.zeros_like(x)
+    n = x.shape[-1]
+    for k in range(K):
+        y += taps[k] * xp[..., 2 * p - k:2 * p - k + n]
+    return np.moveaxis(y, -1, axis)
+
+
+def gaussian_filter_np(x, kernel_size, std):
+    """Separable Gaussian blur over all axes after (B, C) (reference GaussianFilter, utils/processing.py:112-136)."""
+    w = gaussian_kernel_np(kernel_size, std)
+    y = np.asarray(x, dtype=np.float64)
+    for ax in range(2, y.ndim):
+        y = conv_same_axis_np(y, w, ax)
+    return y
+
+
+def structure_tensor_dips_np(x, dv=1.0, dh=1.0, smooth=0.0):
+    """reference utils/slopes.py:6-48."""
+    x = np.asarray(x, dtype=np.float64)
+    gv = first_derivative_np(x, dv, 2)
+    gh = first_derivative_np(x, dh, 3)
+    gvv, gvh, ghh = gv * gv, gv * gh, gh * gh
+    if smooth > 0:
+        K = 2 * min(x.shape[2], x.shape[3]) // 2 + 1
+        gvv, gvh, ghh = (gaussian_filter_np(t, K, smooth) for t in (gvv, gvh, ghh))
+    t1 = 0.5 * (gvv + ghh)
+    t2 = 0.5 * np.sqrt((gvv - ghh) ** 2 + 4 * gvh ** 2)
+    l1, l2 = t1 + t2, t1 - t2
+    with np.errstate(all="ignore"):
+        phi = np.arctan((l1 - gvv) / gvh)
+        phi[np.isnan(phi)] = 0.0
+        aniso = 1 - l2 / l1
+    return phi, aniso
+
+
+def pocs_np(x, wdata_weight, data, mask, perc):
+    """reference utils/pocs.py:5-19,80-84 with the two-sided FFT pair of main_pocs.py:156-157 (torch.rfft / irfft, onesided=False):
+    threshold real and imaginary parts as independent reals at max * perc / 100."""
+    x = np.asarray(x, dtype=np.float64)
+    axes = tuple(range(2, x.ndim))
+    X = np.fft.fftn(x, axes=axes)
+    re, im = X.real.copy(), X.imag.copy()
+    th = max(re.max(), im.max()) * perc / 100.0
+    re = re * ((re > th).astype(float) + (re < -th).astype(float))
+    im = im * ((im > th).astype(float) + (im < -th).astype(float))
+    xr = np.fft.ifftn(re + 1j * im, axes=axes).real
+    return wdata_weight * data + (1.0 - wdata_weight * mask) * xr, th

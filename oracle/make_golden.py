@@ -488,6 +488,123 @@ def gen_host():
     save("host", out)
 
 
+def gen_lines():
+    """BASELINE configs[3] data: the shipped 2-D section datasets/lines (170,100,1) with its random66 mask, driven through the
+    reference Interpolator as --datadim 2d, and tiled to a (170,100,8) volume (the section shifted one trace per slice) cut into
+    2.5-D slabs of 4 slices (--datadim 2.5d --imgchannel 4 --slice tx: the slice axis becomes the channel axis)."""
+    orig = np.load(os.path.join(ref_shim.REFERENCE_ROOT, "datasets/lines/original.npy")).astype(np.float64)
+    m66 = np.load(os.path.join(ref_shim.REFERENCE_ROOT, "datasets/lines/random66.npy")).astype(np.float64)
+    tiny = ["--filters", "4", "8", "16", "--skip", "4", "8", "--inputdepth", "8", "--upsample", "linear", "--gain", "1"]
+    save("net_lines2d_tiny", run_reference_interpolator(["--imgdir", "/nonexistent", "--datadim", "2d"] + tiny, orig, m66, 2, "lines 2d"))
+    slab = np.stack([np.roll(orig[..., 0], k, axis=1) for k in range(4)], axis=-1)
+    mslab = np.stack([np.roll(m66[..., 0], 3 * k, axis=1) for k in range(4)], axis=-1)
+    save("net_lines25d_tiny", run_reference_interpolator(["--imgdir", "/nonexistent", "--datadim", "2.5d", "--imgchannel", "4", "--slice", "tx"] + tiny,
+                                                         slab, mslab, 2, "lines 2.5d"))
+
+
+def gen_checkpoint():
+    """A checkpoint PRODUCED BY THE REFERENCE (main.py:238-240 torch.save(state_dict) + utils/generic.py:46 write_args) for the
+    transfer-learning flow --netdir (main.py:101-110): tests/golden/ckpt_ref/{args.txt, 0_model.pth} + an input/output pair."""
+    main = ref_shim.load_main()
+    import utils as u
+    argv = ["--imgdir", "/nonexistent", "--datadim", "3d", "--filters", "4", "8", "16", "--skip", "4", "8", "--inputdepth", "8",
+            "--upsample", "linear", "--epochs", "2", "--savemodel", "--outdir", "ckpt_ref"]
+    args = ref_shim.parse_args(argv)
+    args.param_noise = False
+    vol = hyperbolic_volume((16, 16, 16), seed=3)
+    msk = trace_mask((16, 16, 16), 0.5, seed=4)
+    u.set_seed(0)
+    d = os.path.join(OUT, "ckpt_ref")
+    os.makedirs(d, exist_ok=True)
+    u.write_args(os.path.join(d, "args.txt"), args)
+    T = main.Interpolator(args, d)
+    with redirect_stdout(io.StringIO()):
+        T.load_data({"image": (vol * 2.0)[..., None], "mask": msk[..., None], "name": "0"})
+        T.build_model()
+        T.build_input()
+        T.optimize()
+        T.save_result()                      # writes 0_run.npy and 0_model.pth
+    os.remove(os.path.join(d, "0_run.npy"))  # only the checkpoint travels
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((1, 8, 16, 16, 16), generator=g)
+    sd = {k: v.clone() for k, v in T.net.state_dict().items()}
+    y = T.net(x)
+    save("ckpt_ref_io", {"x": x, "y": y, "state": {k: npy(v) for k, v in sd.items()}})
+
+
+def gen_operators():
+    """Anti-aliasing add-on operators and the POCS regulariser: reference operators/derivative.py,
+    operators/signal.py, operators/base.py, utils/slopes.py, utils/processing.py:88-181, utils/pocs.py."""
+    import operators as OP
+    import utils as u
+    from utils import slopes as SL, processing as PR, pocs as PC
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    x = torch.randn((1, 2, 9, 7), generator=g)
+    yv = torch.randn((1, 2, 9, 7), generator=g)
+    V = OP.VerticalGrad()
+    out["vgrad"] = {"x": x, "y": V.forward(x), "r": yv, "adj": V.adjoint(yv)}
+    # Chain / Hessian over VerticalGrad
+    Ch = OP.Chain([V, V])
+    out["chain"] = {"x": x, "y": Ch.forward(x), "adj": Ch.adjoint(yv), "hess": OP.Hessian(V).forward(x)}
+    # derivatives: every stencil on every axis of a 4-D tensor, non-unit spacing
+    d = {}
+    xd = torch.randn((2, 3, 6, 5), generator=g)
+    for ax in range(4):
+        for st in ("forward", "backward", "centered"):
+            d["first/ax%d/%s" % (ax, st)] = PR.first_derivative(xd, spacing=0.7, axis=ax, stencil=st)
+        d["second/ax%d" % ax] = PR.second_derivative(xd, spacing=0.7, axis=ax)
+    d["x"] = xd
+    out["deriv"] = d
+    # Hale2D / directional_laplacian
+    xh = torch.randn((1, 1, 12, 10), generator=g)
+    th = (torch.rand((1, 1, 12, 10), generator=g) - 0.5) * 3.0
+    H = SL.Hale2D(th)
+    out["hale"] = {"x": xh, "theta": th, "y": H(xh), "dl": SL.directional_laplacian(xh, th)}
+    xh2 = torch.randn((1, 3, 8, 9), generator=g)
+    th2 = (torch.rand((1, 3, 8, 9), generator=g) - 0.5) * 3.0
+    out["hale_c3"] = {"x": xh2, "theta": th2, "y": SL.Hale2D(th2)(xh2)}
+    # structure tensor dips: plain, with smoothing (channels = 1: the reference's GaussianFilter weight is (1,1,K,K)), and on the
+    # shipped 2-D section datasets/lines/original.npy (BASELINE configs[3] data)
+    xs = torch.randn((1, 1, 14, 10), generator=g)
+    p0, a0 = SL.structure_tensor_dips(xs, dv=1.0, dh=1.0, smooth=0.0)
+    p1, a1 = SL.structure_tensor_dips(xs, dv=0.5, dh=2.0, smooth=1.5)
+    out["dips"] = {"x": xs, "phi0": p0, "aniso0": a0, "phi1": p1, "aniso1": a1}
+    lines = np.load(os.path.join(ref_shim.REFERENCE_ROOT, "datasets/lines/original.npy"))[..., 0].astype(np.float32)
+    xl = torch.from_numpy(lines)[None, None]
+    pl, al = SL.structure_tensor_dips(xl, smooth=2.0)
+    Hl = SL.Hale2D(pl)
+    out["lines"] = {"phi": pl, "aniso": al, "hale_of_data": Hl(xl)}
+    # Gaussian filter 1-D / 2-D
+    xg1 = torch.randn((1, 1, 17), generator=g)
+    xg2 = torch.randn((1, 1, 11, 13), generator=g)
+    out["gauss"] = {"x1": xg1, "y1": PR.GaussianFilter(1, 7, 1, 1.3)(xg1).detach(), "x2": xg2, "y2": PR.GaussianFilter(1, 9, 2, 2.0)(xg2).detach(),
+                    "kernel": PR._gaussian_kernel(9, 2.0)}
+    # VerticalConv
+    wav = PR.ricker_wavelet(9, 2.0).numpy().astype(np.float64) + 0.05 * np.arange(9)      # asymmetric on purpose
+    VC = OP.VerticalConv(wav)
+    xc = torch.randn((1, 3, 15, 6), generator=g)
+    out["vconv"] = {"wavelet": wav, "x": xc, "y": VC.forward(xc), "adj": VC.adjoint(xc)}
+    # POCS: threshold / compute_threshold / POCS.forward with the removed torch.rfft / irfft (onesided=False) emulated by their
+    # documented semantics; the thresholding and weighting are the reference's code
+    def rfft_full(t, nd):
+        return torch.view_as_real(torch.fft.fftn(t, dim=tuple(range(-nd, 0))))
+
+    def irfft_full(T, nd):
+        return torch.fft.ifftn(torch.view_as_complex(T.contiguous()), dim=tuple(range(-nd, 0))).real
+    for tag, shape in (("2d", (1, 1, 16, 12)), ("3d", (1, 1, 8, 6, 10))):
+        nd = len(shape) - 2
+        data = torch.randn(shape, generator=g)
+        mask = (torch.rand(shape, generator=g) > 0.5).float()
+        xo = torch.randn(shape, generator=g)
+        P = PC.POCS(data=data * mask, mask=mask, weight=0.1, thresh_perc=5.0,
+                    forward_fn=lambda t, nd=nd: rfft_full(t, nd), adjoint_fn=lambda T, nd=nd: irfft_full(T, nd))
+        spec = rfft_full(xo, nd)
+        out["pocs_" + tag] = {"data": data * mask, "mask": mask, "x": xo, "y": P(xo), "spec": spec,
+                              "thresh": np.float64(PC.compute_threshold(spec, 5.0)), "thresholded": PC.threshold(spec, PC.compute_threshold(spec, 5.0))}
+    save("operators", out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -496,7 +613,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref_shim.install()
     todo = {"ops": gen_ops, "blocks": gen_blocks, "nets": gen_nets, "structure": gen_structure, "host": gen_host,
-            "unet": gen_unet, "acts": gen_acts}
+            "unet": gen_unet, "acts": gen_acts, "operators": gen_operators, "lines": gen_lines, "checkpoint": gen_checkpoint}
     for k, fn in todo.items():
         if a.only is None or k in a.only:
             fn()

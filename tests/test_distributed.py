@@ -27,7 +27,7 @@ def _fake_optimise(i, patch):
     return patch * 1.5 + 0.01 * i
 
 
-def _worker(rank, world, port, shape, dim, stride, gain, outdir):
+def _worker(rank, world, port, shape, dim, stride, gain, outdir, dynamic=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rng = np.random.RandomState(0)
@@ -35,7 +35,15 @@ def _worker(rank, world, port, shape, dim, stride, gain, outdir):
     pe = u.PatchExtractor(dim=dim, stride=stride)
     patches = pe.extract(vol).reshape((-1,) + dim)
     origins = u.window_origins(shape, dim, stride)
-    rec, mine = P.run_patches(list(patches), origins, shape, dim, stride, gain, _fake_optimise, rank, world)
+    queue, fn = None, _fake_optimise
+    if dynamic:
+        import time
+        queue = P.PatchQueue.for_process_group(len(patches))
+
+        def fn(i, patch):                      # rank 0 is the slow rank: the shared counter must route most patches to rank 1
+            time.sleep(0.05 if rank == 0 else 0.002)
+            return _fake_optimise(i, patch)
+    rec, mine = P.run_patches(list(patches), origins, shape, dim, stride, gain, fn, rank, world, queue=queue)
     np.save(os.path.join(outdir, "rec_%d.npy" % rank), rec)
     np.save(os.path.join(outdir, "mine_%d.npy" % rank), np.array(mine))
     dist.destroy_process_group()
@@ -56,6 +64,31 @@ def test_two_rank_reassembly_matches_oracle(tmp_path, shape, dim, stride):
     np.testing.assert_array_equal(r0, r1)                           # every rank holds the full volume after the all-reduce
     m0, m1 = np.load(tmp_path / "mine_0.npy"), np.load(tmp_path / "mine_1.npy")
     assert sorted(list(m0) + list(m1)) == list(range(len(pa))) and not set(m0) & set(m1)
+
+
+def test_two_rank_shared_queue_balances_uneven_ranks(tmp_path):
+    """PatchQueue over the c10d store: every patch is claimed exactly once, the fast rank takes more of them, and the
+    re-assembled volume is the same as with the static split."""
+    shape, dim, stride, world, gain = (20, 18, 22), (8, 6, 10), (4, 4, 6), 2, 40.0
+    mp.spawn(_worker, args=(world, _free_port(), shape, dim, stride, gain, str(tmp_path), True), nprocs=world, join=True)
+    vol = np.random.RandomState(0).randn(*shape)
+    grid = O.patch_grid(shape, dim, stride)
+    pa = O.extract_patches_nd(vol, dim, stride).reshape((-1,) + dim)
+    outs = np.stack([_fake_optimise(i, p) for i, p in enumerate(pa)]).reshape(grid + dim)
+    ref = O.reconstruct_nd(outs, dim, stride) / gain
+    r0, r1 = np.load(tmp_path / "rec_0.npy"), np.load(tmp_path / "rec_1.npy")
+    np.testing.assert_allclose(r0, ref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_array_equal(r0, r1)
+    m0, m1 = list(np.load(tmp_path / "mine_0.npy")), list(np.load(tmp_path / "mine_1.npy"))
+    assert sorted(m0 + m1) == list(range(len(pa))) and not set(m0) & set(m1)
+    assert len(m1) > 2 * len(m0) > 0, (len(m0), len(m1))
+
+
+def test_patch_queue_local_and_static():
+    q = P.PatchQueue(7)
+    assert q.claim(3) == [0, 1, 2] and q.claim(3) == [3, 4, 5] and q.claim(3) == [6] and q.claim(3) == []
+    q = P.PatchQueue(7, static=(1, 3))
+    assert q.claim(2) == [1, 4] and q.claim(2) == [] and P.PatchQueue(7, static=(0, 3)).claim(9) == [0, 3, 6]
 
 
 def test_shard_balance_config3():

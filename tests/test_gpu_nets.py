@@ -59,7 +59,9 @@ def test_blocks_golden(golden, name):
 
 NETS = ["net_mulresunet3d_tiny_trilinear_mae", "net_mulresunet3d_tiny_nearest_mse", "net_mulresunet3d_tiny_odd",
         "net_skip3d_tiny", "net_mulresunet2d_tiny", "net_mulresunet25d_tiny",
-        "net_mulresunet3d_tiny_elu", "net_mulresunet3d_tiny_tanh_sigmoid"]
+        "net_mulresunet3d_tiny_elu", "net_mulresunet3d_tiny_tanh_sigmoid",
+        # BASELINE configs[3] data: the shipped datasets/lines section as --datadim 2d, and tiled into 2.5-D slabs (4 slices as channels)
+        "net_lines2d_tiny", "net_lines25d_tiny"]
 
 
 def _interpolator(g, epochs):
@@ -101,7 +103,7 @@ def test_net_trajectory(golden, name):
     np.testing.assert_allclose(T.history.pcorr, g["pcorr"], atol=0.1 if "sigmoid" in name else 1e-2)
     assert np.argmin(T.history.loss) == np.argmin(g["loss"])
     assert T.out_best.shape == g["out_best"].shape
-    assert rel(T.out_best, g["out_best"]) < 1e-2
+    assert rel(T.out_best, g["out_best"]) < (2e-2 if "lines" in name else 1e-2)
     fin = T.net.state_dict()
     # (Tanh saturated behind BN weights ~10 leaves near-zero gradients whose SIGN is rounding noise; Adam's first steps
     #  move every weight by ~lr regardless of magnitude, so those weights are not a parity signal — App. D, dead biases)

@@ -1,0 +1,93 @@
+"""The metric's second half — reconstruction SNR vs the reference — by the protocol of SURVEY §8(d)(iv).
+
+The optimisation is chaotic (the reference does not reproduce its own trajectory across CPU thread counts: same seed, 3 vs 2
+threads -> SNR(out_best) 22.68 vs 20.24 dB), so a run-to-run comparison of single trajectories is meaningless
+beyond ~10 iterations (tests/test_gpu_nets.py covers those).  What can be compared is the DISTRIBUTION of the end result:
+
+  tests/golden/snr_spread.npz   recorded by oracle/make_snr_spread.py from the reference's own Interpolator (imported from
+                                /root/reference): (48,32,32) hyperbolic stand-in, 66 % missing traces, default MulResUnet3D,
+                                gain 40, MAE, trilinear, param_noise=False, 1000 Adam iterations, seeds 0..7.
+  here                          the HIP path on the same volume / mask / hyper-parameters, same seeds (bit-identical initial
+                                weights, tests/test_host.py), its own Philox noise stream, 1000 iterations per seed.
+
+Asserted: |mean SNR(out_best) HIP - mean reference| <= 2 standard errors of the difference (tolerance printed in dB), the
+same for the minimum loss, and every run finite.  The dB difference is printed (pytest -s) and recorded in DESIGN.md."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "snr_spread.npz")
+N_SEEDS_HIP = 12
+
+
+def _run_seed(seed, vol, mask, epochs):
+    from deep_prior_interpolation_amd import utils as u
+    from deep_prior_interpolation_amd.main import Interpolator
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    args = parse_arguments(["--imgdir", "synthetic", "--datadim", "3d", "--net", "multiunet", "--inputdepth", "64", "--upsample", "linear",
+                            "--loss", "mae", "--lr", "1e-3", "--gain", "40", "--reg_noise_std", "0.03", "--noise_std", "0.1",
+                            "--epochs", str(epochs), "--gpu", "0"])
+    u.set_seed(seed)
+    T = Interpolator(args, "/tmp", seed=seed)
+    T.load_data({"image": (vol.astype(np.float64) * args.gain)[..., None], "mask": mask.astype(np.float64)[..., None], "name": "0"})
+    T.build_model()
+    T.build_input()
+    T.optimize(verbose=False)
+    target = vol.astype(np.float64) * args.gain
+    ob = np.asarray(T.out_best, dtype=np.float64)
+    assert np.isfinite(ob).all() and np.isfinite(T.history.loss).all()
+    return 10.0 * np.log10(np.sum(target ** 2) / np.sum((target - ob) ** 2)), float(np.min(T.history.loss)), np.array(T.history.snr)
+
+
+def test_snr_of_best_output_matches_reference_distribution():
+    z = np.load(GOLD)
+    vol, mask, epochs = z["volume"], z["mask"].astype(np.float32), int(z["epochs"][0])
+    ref_snr, ref_min = z["snr_out_best"].astype(np.float64), z["loss_min"].astype(np.float64)
+    assert len(ref_snr) >= 5 and epochs == 1000
+    got = [_run_seed(s, vol, mask, epochs) for s in range(N_SEEDS_HIP)]
+    snr = np.array([g[0] for g in got])
+    lmin = np.array([g[1] for g in got])
+
+    def cmp(a, b, what, unit):
+        da = a.mean() - b.mean()
+        se = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
+        print("%s: HIP %.4g +- %.3g (n=%d)   reference %.4g +- %.3g (n=%d)   difference %+.3g %s, tolerance 2 s.e. = %.3g %s"
+              % (what, a.mean(), a.std(ddof=1), len(a), b.mean(), b.std(ddof=1), len(b), da, unit, 2 * se, unit))
+        return da, se
+    d_snr, se_snr = cmp(snr, ref_snr, "SNR(out_best)", "dB")
+    d_min, se_min = cmp(lmin, ref_min, "min loss", "")
+    assert abs(d_snr) <= 2.0 * se_snr, (d_snr, se_snr)
+    assert abs(d_min) <= 2.0 * se_min, (d_min, se_min)
+    # the spread itself is a property of the method: the HIP path must not be markedly noisier or tighter than the reference
+    assert 0.4 < snr.std(ddof=1) / ref_snr.std(ddof=1) < 2.5
+    # trajectory shape: SNR along the way (mean over seeds) within the reference's band at a few checkpoints
+    ref_traj = z["snr"].astype(np.float64)
+    my_traj = np.stack([g[2] for g in got])
+    for it in (100, 250, 500, 750, 999):
+        a, b = my_traj[:, it - 10:it + 1].mean(axis=1), ref_traj[:, it - 10:it + 1].mean(axis=1)
+        se = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
+        print("iteration %4d: SNR HIP %.2f dB, reference %.2f dB (s.e. of difference %.2f)" % (it, a.mean(), b.mean(), se))
+        assert abs(a.mean() - b.mean()) <= 3.0 * se + 0.3
+
+
+def test_full_length_run_at_bench_geometry():
+    """One complete optimisation as the reference's notebook runs it (proof_of_concept_3D.ipynb:354-358, main.py:195-220): patch
+    256x128x128, default net, 3000 Adam iterations, on the synthetic stand-in with 66 % missing traces.  ~2 minutes of GPU.
+    The trajectory of the committed run is profiles/r02_full_run_256x128x128.json (SNR(out_best) 10.5 dB); kernels are
+    deterministic, but any kernel change moves the chaotic trajectory within the +-1.1 dB seed spread, hence the 9 dB bar."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "gpurun_out", "full_run_test.json")
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "full_run.py"), "--out", out], timeout=900)
+    with open(out) as fp:
+        r = json.load(fp)
+    print("full run: %d iterations in %.1f s (%.2f it/s), SNR(out_best) %.2f dB, min loss %.4f at %d, last-50 SNR %.2f +- %.2f dB"
+          % (r["epochs"], r["seconds"], r["it_per_s"], r["snr_out_best_db"], r["loss_min"], r["argmin"], r["snr_last50_mean"], r["snr_last50_std"]))
+    assert r["epochs"] == 3000 and r["finite"]
+    assert r["snr_out_best_db"] > 9.0
+    assert r["loss"][-1] < 0.25 * r["loss"][0]
+    assert r["it_per_s"] > 20.0

@@ -147,7 +147,9 @@ def cfg_from_args(a, ndim=None):
 
 NETS = ["net_mulresunet3d_tiny_trilinear_mae", "net_mulresunet3d_tiny_nearest_mse", "net_mulresunet3d_tiny_odd",
         "net_skip3d_tiny", "net_mulresunet2d_tiny", "net_mulresunet25d_tiny",
-        "net_mulresunet3d_tiny_elu", "net_mulresunet3d_tiny_tanh_sigmoid"]
+        "net_mulresunet3d_tiny_elu", "net_mulresunet3d_tiny_tanh_sigmoid",
+        # BASELINE configs[3] data: the shipped datasets/lines section as --datadim 2d, and tiled into 2.5-D slabs (4 slices as channels)
+        "net_lines2d_tiny", "net_lines25d_tiny"]
 
 
 def _load_net_case(g):
@@ -189,7 +191,9 @@ def test_net_trajectory(golden, name):
     ob = h["out_best"].numpy()
     ob = ob.squeeze() if ob.ndim > 4 else ob[0].transpose(1, 2, 0)     # main.py:175-176
     assert ob.shape == g["out_best"].shape
-    assert relnorm(ob, g["out_best"]) < 5e-3
+    # (the lines section runs at gain 1 — signal ~0.04 — and the third iterate already carries the amplified rounding differences of
+    #  two Adam steps: 0.8 % between 4 and 8 CPU threads of the reference's own torch kernels)
+    assert relnorm(ob, g["out_best"]) < (2e-2 if "lines" in name else 5e-3)
     # weights that carry real gradient agree; dead conv biases may flip sign
     fin = S.state_dict()
     # (Tanh saturated behind BN weights ~10 leaves near-zero gradients whose SIGN is rounding noise; Adam's first steps
@@ -301,3 +305,53 @@ def test_unet(golden, mode):
         else:
             assert relnorm(S.P[k].grad, v) < 2e-4, k
     assert S.used == set(S.P.keys())
+
+
+# ---- anti-aliasing operators / POCS: the oracle's numpy restatements against vectors recorded from the reference -------------
+def test_operator_oracle_vs_reference(golden):
+    g = golden("operators")
+    v = g["vgrad"]
+    np.testing.assert_allclose(O.vertical_grad_np(v["x"]), v["y"], rtol=0, atol=0)
+    np.testing.assert_allclose(O.vertical_grad_np(v["r"], adjoint=True), v["adj"], rtol=0, atol=1e-7)
+    c = g["chain"]
+    np.testing.assert_allclose(O.vertical_grad_np(O.vertical_grad_np(c["x"])), c["y"], atol=1e-6)
+    np.testing.assert_allclose(O.vertical_grad_np(O.vertical_grad_np(c["x"]), adjoint=True), c["hess"], atol=1e-6)
+    d = g["deriv"]
+    for ax in range(4):
+        for st in ("forward", "backward", "centered"):
+            np.testing.assert_allclose(O.first_derivative_np(d["x"].astype(np.float64), 0.7, ax, st), d["first"]["ax%d" % ax][st], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(O.second_derivative_np(d["x"].astype(np.float64), 0.7, ax), d["second"]["ax%d" % ax], rtol=1e-5, atol=1e-5)
+    for tag in ("hale", "hale_c3"):
+        h = g[tag]
+        np.testing.assert_allclose(O.hale2d_np(h["x"].astype(np.float64), h["theta"].astype(np.float64)), h["y"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(g["hale"]["y"], g["hale"]["dl"])
+    s = g["dips"]
+    p0, a0 = O.structure_tensor_dips_np(s["x"])
+    np.testing.assert_allclose(p0, s["phi0"], atol=2e-4)
+    p1, a1 = O.structure_tensor_dips_np(s["x"], 0.5, 2.0, 1.5)
+    np.testing.assert_allclose(p1, s["phi1"], atol=2e-4)
+    np.testing.assert_allclose(a1, s["aniso1"], rtol=1e-3, atol=1e-4)
+    ga = g["gauss"]
+    np.testing.assert_allclose(O.gaussian_kernel_np(9, 2.0), ga["kernel"], rtol=1e-6)
+    np.testing.assert_allclose(O.gaussian_filter_np(ga["x1"], 7, 1.3), ga["y1"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(O.gaussian_filter_np(ga["x2"], 9, 2.0), ga["y2"], rtol=1e-5, atol=1e-5)
+    vc = g["vconv"]
+    np.testing.assert_allclose(O.conv_same_axis_np(vc["x"], vc["wavelet"] / 2, 2), vc["y"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(O.conv_same_axis_np(vc["x"], vc["wavelet"][::-1] / 2, 2), vc["adj"], rtol=1e-5, atol=1e-5)
+    for tag in ("pocs_2d", "pocs_3d"):
+        p = g[tag]
+        y, th = O.pocs_np(p["x"], 0.1, p["data"], p["mask"], 5.0)
+        assert abs(th - float(p["thresh"])) < 1e-5 * abs(th)
+        np.testing.assert_allclose(y, p["y"], rtol=1e-4, atol=1e-4)
+
+
+def test_operator_adjoints_are_transposes():
+    """The adjoint restatements (and, through the GPU tests, the adjoint kernels) are the exact transposes of the forward maps."""
+    rng = np.random.RandomState(0)
+    shape = (1, 2, 4, 5)
+    A = O.linear_operator_matrix(O.vertical_grad_np, shape)
+    At = O.linear_operator_matrix(lambda t: O.vertical_grad_np(t, adjoint=True), shape)
+    np.testing.assert_allclose(At, A.T, atol=1e-12)
+    th = rng.randn(*shape)
+    H = O.linear_operator_matrix(lambda t: O.hale2d_np(t, th), shape)
+    assert np.abs(H - H.T).max() > 1e-3            # the reference's operator is NOT symmetric (forward differences applied twice)
