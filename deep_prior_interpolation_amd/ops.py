@@ -454,20 +454,12 @@ def _cba_raw(d, x, in_chain, w, b, bn, slope, r_out, mi_out, chain_out):
                     bn.num_batches_tracked, mi_out, chain_out)
 
 
-_zero_grads = {}
-
-
 def _zeros_like_or_none(b):
-    """Gradient of a conv bias that feeds a BatchNorm: identically zero.  One read-only zero tensor per bias is kept and
-    handed out every iteration (no fill launch); optimisers only read .grad."""
-    if b is None:
-        return None
-    key = (b.data_ptr(), tuple(b.shape), str(b.device))
-    z = _zero_grads.get(key)
-    if z is None:
-        z = torch.zeros_like(b)
-        _zero_grads[key] = z
-    return z
+    """Gradient of a conv bias that feeds a BatchNorm: identically zero — reported as None, which autograd and
+    the optimisers treat as "no gradient" (torch.optim.Adam and FusedAdam skip such parameters; with zero moments the Adam
+    update of a zero gradient is exactly 0, so the trajectory is the same).  Handing out cached zero tensors instead made
+    autograd clone each of them every iteration (48 device-to-device copies)."""
+    return None
 
 
 class Block3dFn(torch.autograd.Function):

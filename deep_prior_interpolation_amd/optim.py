@@ -31,48 +31,69 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros(int(offs[-1]), dtype=torch.float32, device=dev)
         self._m = [self.exp_avg[offs[i]:offs[i + 1]] for i in range(len(ps))]
         self._v = [self.exp_avg_sq[offs[i]:offs[i + 1]] for i in range(len(ps))]
-        self._sizes = torch.tensor(sizes, dtype=torch.int64, device=dev)
         self.step_lr = torch.tensor([0.0, lr], dtype=torch.float32, device=dev)
         self.active = torch.ones(1, dtype=torch.int32, device=dev)
-        self._table_host = torch.empty(len(ps) * 4, dtype=torch.int64).pin_memory()
-        self._table = torch.empty(len(ps) * 4, dtype=torch.int64, device=dev)
+        self._table_host = torch.empty(len(ps) * 5, dtype=torch.int64).pin_memory()     # 4 pointers + 1 size per tensor
+        self._table = torch.empty(len(ps) * 5, dtype=torch.int64, device=dev)
         self._table_key = None
+        self._n_active = 0
+        self._capture_tables = []
         self._table_copied = None       # event recorded after the last async H2D copy out of _table_host
 
     def set_lr(self, lr):
         self.param_groups[0]["lr"] = lr
         self.step_lr[1] = lr
 
-    def _refresh_table(self):
-        key = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in self._params)
-        if key == self._table_key:
-            return
-        rows = []
+    def _rows(self):
+        """(pointer rows, sizes) of the parameters that received a gradient.  Parameters whose gradient is None are skipped, as
+        torch.optim.Adam does (main.py:200): the conv biases that feed a BatchNorm have an analytically zero gradient (SURVEY
+        App. D) and the fused nodes return None for them — with zero moments their Adam update is exactly 0 either way."""
+        rows, sizes = [], []
         for p, m, v in zip(self._params, self._m, self._v):
-            if p.grad is None:
-                raise _lib.DpiError("FusedAdam.step: a parameter has no gradient")
             g = p.grad
+            if g is None:
+                continue
             if not g.is_contiguous():
                 raise _lib.DpiError("FusedAdam.step: non-contiguous gradient")
             rows += [p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()]
+            sizes.append(p.numel())
+        if not sizes:
+            raise _lib.DpiError("FusedAdam.step: no parameter has a gradient")
+        return rows, sizes
+
+    def _refresh_table(self):
+        """Device table {p, g, m, v} x tensors for this step; returns (table, sizes, count)."""
+        key = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in self._params)
         if torch.cuda.is_current_stream_capturing():
-            # an H2D copy node would re-read the pinned staging buffer on every replay — after later eager steps rewrote it.
-            # Callers run one eager iteration first (Interpolator.graph_prepare), so the table is normally current here.
-            raise _lib.DpiError("FusedAdam.step: gradient buffers changed inside a graph capture; run one eager step first")
-        if self._table_copied is not None:
-            self._table_copied.synchronize()         # the previous async copy must have left the pinned buffer
-        self._table_host.copy_(torch.tensor(rows, dtype=torch.int64))
-        self._table.copy_(self._table_host, non_blocking=True)
-        self._table_copied = torch.cuda.Event()
-        self._table_copied.record()
-        self._table_key = key
+            # Inside a hipGraph capture the gradients live in the graph's private pool (other addresses than in eager mode) and the
+            # H2D copy becomes a graph node that re-reads its host buffer on EVERY replay: give the capture its own pinned staging
+            # buffer and device table, kept alive with the optimiser, so later eager steps cannot overwrite what a replay reads.
+            rows, sizes = self._rows()
+            host = torch.tensor(rows + sizes, dtype=torch.int64).pin_memory()
+            dev = torch.empty(len(rows) + len(sizes), dtype=torch.int64, device=self._table.device)
+            dev.copy_(host, non_blocking=True)
+            self._capture_tables.append((host, dev))
+            n = len(sizes)
+            return dev[:4 * n], dev[4 * n:], n
+        if key != self._table_key:
+            rows, sizes = self._rows()
+            n = len(sizes)
+            if self._table_copied is not None:
+                self._table_copied.synchronize()         # the previous async copy must have left the pinned buffer
+            self._table_host[:5 * n].copy_(torch.tensor(rows + sizes, dtype=torch.int64))
+            self._table[:5 * n].copy_(self._table_host[:5 * n], non_blocking=True)
+            self._table_copied = torch.cuda.Event()
+            self._table_copied.record()
+            self._table_key, self._n_active = key, n
+        n = self._n_active
+        return self._table[:4 * n], self._table[4 * n:5 * n], n
 
     @torch.no_grad()
     def step(self, closure=None):
-        self._refresh_table()
+        table, sizes, n = self._refresh_table()
         self.step_lr[0] += 1.0
         b1, b2 = self.param_groups[0]["betas"]
-        check(_lib.load().dpi_adam_multi(ptr(self._table), ptr(self._sizes), len(self._params), ptr(self.step_lr),
+        check(_lib.load().dpi_adam_multi(ptr(table), ptr(sizes), n, ptr(self.step_lr),
                                          b1, b2, self.param_groups[0]["eps"], ptr(self.active), stream()), "dpi_adam_multi")
 
 

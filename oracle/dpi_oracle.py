@@ -631,15 +631,16 @@ def gaussian_filter_np(x, kernel_size, std):
     return y
 
 
-def structure_tensor_dips_np(x, dv=1.0, dh=1.0, smooth=0.0):
-    """reference utils/slopes.py:6-48."""
-    x = np.asarray(x, dtype=np.float64)
+def structure_tensor_dips_np(x, dv=1.0, dh=1.0, smooth=0.0, dtype=np.float64):
+    """reference utils/slopes.py:6-48.  dtype=np.float32 mimics the reference's own arithmetic on fp32 tensors: the dip angle
+    atan((l1 - gvv) / gvh) cancels catastrophically where the tensor is nearly diagonal, so fp32 and fp64 legitimately differ there."""
+    x = np.asarray(x, dtype=dtype)
     gv = first_derivative_np(x, dv, 2)
     gh = first_derivative_np(x, dh, 3)
     gvv, gvh, ghh = gv * gv, gv * gh, gh * gh
     if smooth > 0:
         K = 2 * min(x.shape[2], x.shape[3]) // 2 + 1
-        gvv, gvh, ghh = (gaussian_filter_np(t, K, smooth) for t in (gvv, gvh, ghh))
+        gvv, gvh, ghh = (gaussian_filter_np(t, K, smooth).astype(dtype) for t in (gvv, gvh, ghh))
     t1 = 0.5 * (gvv + ghh)
     t2 = 0.5 * np.sqrt((gvv - ghh) ** 2 + 4 * gvh ** 2)
     l1, l2 = t1 + t2, t1 - t2

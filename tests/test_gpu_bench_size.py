@@ -173,9 +173,10 @@ def test_default_net_fused_vs_leaf_at_128x64x64():
         finally:
             M.FUSE_BLOCKS = True
         torch.cuda.synchronize()
-        res.append((out.detach(), float(loss.detach()), {k: p.grad.detach().clone() for k, p in n.named_parameters()}))
+        res.append((out.detach(), float(loss.detach()), {k: p.grad.detach().clone() for k, p in n.named_parameters() if p.grad is not None}))
     (o1, l1, g1), (o2, l2, g2) = res
     assert rel(o1, o2) < 5e-5
     assert abs(l1 - l2) < 1e-5 * abs(l2)
     errs = [rel(g1[k], g2[k]) for k in g1 if g1[k].ndim > 1]
+    print("fused vs leaf at 128x64x64: weight-gradient error median %.2e max %.2e" % (np.median(errs), max(errs)))
     assert np.median(errs) < 1e-3 and max(errs) < 5e-2, (np.median(errs), max(errs))

