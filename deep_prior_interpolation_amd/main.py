@@ -268,6 +268,7 @@ class Interpolator:
 
         one_iteration()                                  # iteration 0, eager (also warms every lazy cache)
         torch.cuda.synchronize(dev)
+        opt.prepare_capture()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             one_iteration()                              # recorded, not executed

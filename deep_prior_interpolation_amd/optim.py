@@ -38,7 +38,13 @@ class FusedAdam(torch.optim.Optimizer):
         self._table_key = None
         self._n_active = 0
         self._capture_tables = []
+        self._capture_ready = None
         self._table_copied = None       # event recorded after the last async H2D copy out of _table_host
+
+    def prepare_capture(self):
+        """Allocate the pinned staging buffer + device table the next captured step() will use (see _refresh_table)."""
+        n = len(self._params) * 5
+        self._capture_ready = (torch.empty(n, dtype=torch.int64).pin_memory(), torch.empty(n, dtype=torch.int64, device=self._table.device))
 
     def set_lr(self, lr):
         self.param_groups[0]["lr"] = lr
@@ -68,13 +74,17 @@ class FusedAdam(torch.optim.Optimizer):
             # Inside a hipGraph capture the gradients live in the graph's private pool (other addresses than in eager mode) and the
             # H2D copy becomes a graph node that re-reads its host buffer on EVERY replay: give the capture its own pinned staging
             # buffer and device table, kept alive with the optimiser, so later eager steps cannot overwrite what a replay reads.
+            # (Pinned memory cannot be allocated while a stream is capturing: prepare_capture() did that beforehand.)
+            if self._capture_ready is None:
+                raise _lib.DpiError("FusedAdam.step inside a graph capture: call prepare_capture() before torch.cuda.graph(...)")
+            host, dev = self._capture_ready
+            self._capture_ready = None
             rows, sizes = self._rows()
-            host = torch.tensor(rows + sizes, dtype=torch.int64).pin_memory()
-            dev = torch.empty(len(rows) + len(sizes), dtype=torch.int64, device=self._table.device)
-            dev.copy_(host, non_blocking=True)
-            self._capture_tables.append((host, dev))
             n = len(sizes)
-            return dev[:4 * n], dev[4 * n:], n
+            host[:5 * n].copy_(torch.tensor(rows + sizes, dtype=torch.int64))
+            dev[:5 * n].copy_(host[:5 * n], non_blocking=True)
+            self._capture_tables.append((host, dev))
+            return dev[:4 * n], dev[4 * n:5 * n], n
         if key != self._table_key:
             rows, sizes = self._rows()
             n = len(sizes)
