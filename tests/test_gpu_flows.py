@@ -59,7 +59,7 @@ def _survey(tmp_path, shape=(32, 16, 16)):
     np.save(d / "original.npy", u.hyperbolic_volume(shape, seed=5).astype(np.float32))
     np.save(d / "mask.npy", u.random_trace_mask(shape, 0.5, seed=6).astype(np.float32))
     return ["--imgdir", str(d), "--imgname", "original.npy", "--maskname", "mask.npy", "--datadim", "3d", "--patch_shape", "16", "16", "16",
-            "--patch_stride", "16", "16", "16", "--filters", "4", "8", "--skip", "4", "--inputdepth", "8", "--upsample", "linear", "--gpu", "0"]
+            "--patch_stride", "16", "16", "16", "--filters", "4", "8", "--skip", "4", "--inputdepth", "8", "--upsample", "linear", "--gain", "2", "--gpu", "0"]
 
 
 def test_savemodel_then_netdir_round_trip(tmp_path, monkeypatch):
@@ -78,6 +78,7 @@ def test_savemodel_then_netdir_round_trip(tmp_path, monkeypatch):
     second = [np.load("results/second/%d_run.npy" % i, allow_pickle=True).item() for i in range(2)]
     for i in range(2):
         l_first, l_second = first[i]["history"].loss, second[i]["history"].loss
+        print("patch %d: first run", i, ["%.4f" % v for v in l_first], "second run (loaded)", ["%.4f" % v for v in l_second])
         assert l_second[0] < 0.8 * l_first[0]                   # continues from the optimised weights, not from scratch
         assert abs(l_second[0] - l_first[-1]) < 0.35 * l_first[-1]
     # the checkpoint written by the second run loads into a fresh net with identical keys
