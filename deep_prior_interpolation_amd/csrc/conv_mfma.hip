@@ -960,13 +960,31 @@ static MfmaBwPlan mfma_bw_plan(const dpi_conv_desc* d, bool swap = false) {
   p.ntiles = dpi_mfma_tiles(d, p.nr, p.nh, &p.ntd, &p.nth, &p.ntw);
   const size_t per = (size_t)d->Cout * d->Cin * d->kd * 9;
   const size_t max_chunks_mem = per ? ((size_t)32 << 20) / per : 1;
-  const size_t blocks_other = swap ? (size_t)cdiv(d->Cout, 4) * cdiv(d->Cin, 16) : (size_t)cdiv(d->Cin, 4) * cdiv(d->Cout, 16);
-  size_t want = 2304 / blocks_other;   // 3 workgroups per CU x 256 CUs x 3 full rounds (a 4th, partly filled round costs ~10 %)
-  if (want < 1) want = 1;
-  if (want > (size_t)p.ntiles) want = p.ntiles;
-  if (want > max_chunks_mem) want = max_chunks_mem;
-  if (want < 1) want = 1;
-  p.tiles_per_chunk = (int)cdivz(p.ntiles, want);
+  const int staged = swap ? d->Cout : d->Cin, rows = swap ? d->Cin : d->Cout;
+  size_t groups = (size_t)cdiv(staged, 4);
+  // channel counts 4m + 1 run their one-channel last group as a separate, much shorter launch (see the dispatcher below):
+  // the occupancy rounds that matter are those of the main launch
+  if (d->stride == 1 && d->kd == 3 && (staged & 3) == 1 && staged > 4) groups -= 1;
+  const size_t blocks_other = groups * cdiv(rows, 16);
+  // Workgroups run in rounds of 3 per CU x 256 CUs (44 KB LDS each); every round lasts tiles_per_chunk tile-times, so the
+  // launch costs ceil(workgroups / 768) x tiles_per_chunk (+ a per-workgroup prologue / cross-wave reduction ~ half a tile).
+  // Pick the chunk length that minimises it among those giving 1.5 .. 4 rounds (measured 25 -> 16: 316 chunks = 2.47 rounds
+  // of 13 tiles -> 373 chunks = 2.91 rounds of 11).
+  const size_t round_wgs = d->stride == 1 ? 768 : 512;               // stride 2: 65 KB LDS per workgroup -> 2 per CU
+  size_t best_tpc = 0;
+  double best_cost = 1e30;
+  for (size_t tpc = 1; tpc <= (size_t)p.ntiles; ++tpc) {
+    const size_t chunks = cdivz((size_t)p.ntiles, tpc);
+    if (chunks > max_chunks_mem && tpc < (size_t)p.ntiles) continue;
+    const size_t wgs = chunks * blocks_other;
+    const size_t rounds = cdivz(wgs, round_wgs);
+    if (rounds > 4 && tpc < (size_t)p.ntiles) continue;              // more, shorter chunks only add reduction traffic
+    const double cost = (double)rounds * ((double)tpc + 0.5);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best_tpc = tpc; }
+    if (wgs <= round_wgs / 2) break;                                   // fewer workgroups than half a round: stop shrinking
+  }
+  if (best_tpc == 0) best_tpc = p.ntiles;
+  p.tiles_per_chunk = (int)best_tpc;
   p.nchunks = cdiv(p.ntiles, p.tiles_per_chunk);
   return p;
 }
