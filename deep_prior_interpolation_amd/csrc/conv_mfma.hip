@@ -419,6 +419,11 @@ struct BwMArgs {
   // channels (64 -> 4: M = 4 of 16 rows the usual way round) this fills the tile: M = 16 input channels, N = 4 co x 27.
   int swap;
   int y0;                   // first 4-channel group of this launch (blockIdx.y is relative to it)
+  // XCD-aware order (ngroups > 0): the launch is 1-D over L = xcd + 8 * (group + ngroups * (chunk / 8)) with chunk % 8 = xcd.
+  // Workgroup L runs on XCD L % 8 (dispatch is round-robin over the 8 XCDs), so the ngroups workgroups that share a chunk's dY
+  // rows — and the chunk's X halo rows — run back to back on ONE XCD and find them in its L2 instead of re-reading HBM
+  // (measured before: 3.4 GB fetched per launch for 0.69 GB algorithmic on 25 -> 16).
+  int ngroups, nchunks;
 };
 
 // TC != 0: the launch covers a final group that holds only TC real channels (Cin = 4m + 1: TC = 1) and computes just their
@@ -449,7 +454,14 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
   const int lk = lane >> 4, lj = lane & 15;
   const int wch = lane >> 2, wp = lane & 3;   // dY fetch mapping: channel, float4 piece
   float* __restrict__ dyw = dyl[wid];
-  const int c0 = (blockIdx.y + a.y0) * 4, n0 = blockIdx.z * 16;
+  int chunk = blockIdx.x, group = blockIdx.y;
+  if (a.ngroups > 0) {
+    const int L = blockIdx.x, r = L >> 3;
+    group = r % a.ngroups;
+    chunk = (r / a.ngroups) * 8 + (L & 7);
+    if (chunk >= a.nchunks) return;
+  }
+  const int c0 = (group + a.y0) * 4, n0 = blockIdx.z * 16;
   const size_t V = (size_t)a.D * a.H * a.W;
   const int Do = (a.D + 2 * PD - KD) / G::SD + 1, Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
   const size_t Vo = (size_t)Do * Ho * Wo;
@@ -472,7 +484,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
 #pragma unroll
   for (int t = 0; t < NTQ; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int t_begin = blockIdx.x * a.tiles_per_chunk;
+  const int t_begin = chunk * a.tiles_per_chunk;
   const int t_end = min(t_begin + a.tiles_per_chunk, a.ntiles);
   int goff[G::E], loff[G::E];
   float sr[4][G::E];
@@ -566,8 +578,8 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
     const float sum = red[e] + red[e + NTQ * 256] + red[e + 2 * NTQ * 256] + red[e + 3 * NTQ * 256];
     const int co = n0 + 4 * (l >> 4) + r, q = t * 16 + (l & 15), ci = c0 + q / TAPS, tap = q % TAPS;
     if (co < a.Cout && q < NQ && ci < a.Cin) {
-      if (a.swap) a.ws[(((size_t)blockIdx.x * a.Cin + ci) * a.Cout + co) * TAPS + (TAPS - 1 - tap)] = sum;   // (staged, A) = (co, ci)
-      else a.ws[(((size_t)blockIdx.x * a.Cout + co) * a.Cin + ci) * TAPS + tap] = sum;
+      if (a.swap) a.ws[(((size_t)chunk * a.Cin + ci) * a.Cout + co) * TAPS + (TAPS - 1 - tap)] = sum;   // (staged, A) = (co, ci)
+      else a.ws[(((size_t)chunk * a.Cout + co) * a.Cin + ci) * TAPS + tap] = sum;
     }
   }
 }
@@ -952,6 +964,12 @@ static bool mfma_bw_swap_better(const dpi_conv_desc* d) {
   return util(d->Cin, d->Cout) > 1.15 * util(d->Cout, d->Cin);
 }
 
+static int g_bw_want = 2304;        // tuning knobs (dpi_set_bw_tuning): workgroups aimed at, XCD-aware workgroup order on/off
+static int g_bw_xcd_order = 1;
+extern "C" void dpi_set_bw_tuning(int want_workgroups, int xcd_order) {
+  if (want_workgroups > 0) g_bw_want = want_workgroups;
+  if (xcd_order >= 0) g_bw_xcd_order = xcd_order;
+}
 struct MfmaBwPlan { int nchunks, tiles_per_chunk, ntiles, ntd, nth, ntw, nr, nh; };
 static MfmaBwPlan mfma_bw_plan(const dpi_conv_desc* d, bool swap = false) {
   MfmaBwPlan p{};
@@ -960,31 +978,17 @@ static MfmaBwPlan mfma_bw_plan(const dpi_conv_desc* d, bool swap = false) {
   p.ntiles = dpi_mfma_tiles(d, p.nr, p.nh, &p.ntd, &p.nth, &p.ntw);
   const size_t per = (size_t)d->Cout * d->Cin * d->kd * 9;
   const size_t max_chunks_mem = per ? ((size_t)32 << 20) / per : 1;
-  const int staged = swap ? d->Cout : d->Cin, rows = swap ? d->Cin : d->Cout;
-  size_t groups = (size_t)cdiv(staged, 4);
-  // channel counts 4m + 1 run their one-channel last group as a separate, much shorter launch (see the dispatcher below):
-  // the occupancy rounds that matter are those of the main launch
-  if (d->stride == 1 && d->kd == 3 && (staged & 3) == 1 && staged > 4) groups -= 1;
-  const size_t blocks_other = groups * cdiv(rows, 16);
-  // Workgroups run in rounds of 3 per CU x 256 CUs (44 KB LDS each); every round lasts tiles_per_chunk tile-times, so the
-  // launch costs ceil(workgroups / 768) x tiles_per_chunk (+ a per-workgroup prologue / cross-wave reduction ~ half a tile).
-  // Pick the chunk length that minimises it among those giving 1.5 .. 4 rounds (measured 25 -> 16: 316 chunks = 2.47 rounds
-  // of 13 tiles -> 373 chunks = 2.91 rounds of 11).
-  const size_t round_wgs = d->stride == 1 ? 768 : 512;               // stride 2: 65 KB LDS per workgroup -> 2 per CU
-  size_t best_tpc = 0;
-  double best_cost = 1e30;
-  for (size_t tpc = 1; tpc <= (size_t)p.ntiles; ++tpc) {
-    const size_t chunks = cdivz((size_t)p.ntiles, tpc);
-    if (chunks > max_chunks_mem && tpc < (size_t)p.ntiles) continue;
-    const size_t wgs = chunks * blocks_other;
-    const size_t rounds = cdivz(wgs, round_wgs);
-    if (rounds > 4 && tpc < (size_t)p.ntiles) continue;              // more, shorter chunks only add reduction traffic
-    const double cost = (double)rounds * ((double)tpc + 0.5);
-    if (cost < best_cost - 1e-9) { best_cost = cost; best_tpc = tpc; }
-    if (wgs <= round_wgs / 2) break;                                   // fewer workgroups than half a round: stop shrinking
-  }
-  if (best_tpc == 0) best_tpc = p.ntiles;
-  p.tiles_per_chunk = (int)best_tpc;
+  const size_t blocks_other = swap ? (size_t)cdiv(d->Cout, 4) * cdiv(d->Cin, 16) : (size_t)cdiv(d->Cin, 4) * cdiv(d->Cout, 16);
+  // ~2304 workgroups (3 per CU x 256 CUs x 3) measured best on the full-resolution layers.  (A model that picks the chunk
+  // length by whole occupancy rounds of the main launch was measured 14-17 % SLOWER on every layer, round 2: the kernel is
+  // not round-quantised — its limiter is the dY / X re-read traffic, see the XCD-aware workgroup order in the kernel.)
+  size_t want = (size_t)g_bw_want / blocks_other;
+  if (want < 1) want = 1;
+  if (want > (size_t)p.ntiles) want = p.ntiles;
+  if (want > max_chunks_mem) want = max_chunks_mem;
+  if (want < 1) want = 1;
+  if (g_bw_xcd_order && want > 8) want = want / 8 * 8;        // whole groups of 8 chunks (one per XCD)
+  p.tiles_per_chunk = (int)cdivz(p.ntiles, want);
   p.nchunks = cdiv(p.ntiles, p.tiles_per_chunk);
   return p;
 }
@@ -999,27 +1003,38 @@ int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const f
                                  hipStream_t st) {
   const bool swap = dpi_conv_bwd_weight_mfma_swapped(d, chain);     // the chain can only be applied to the staged tensor
   const MfmaBwPlan p = mfma_bw_plan(d, swap);
-  BwMArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk, 0, 0};
+  BwMArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk, 0, 0, 0, p.nchunks};
   dim3 grid(p.nchunks, cdiv(d->Cin, 4), cdiv(d->Cout, 16));
   if (swap) {
     a.x = dy; a.chain = nullptr; a.dy = x; a.Cin = d->Cout; a.Cout = d->Cin; a.swap = 1;
     grid = dim3(p.nchunks, cdiv(d->Cout, 4), cdiv(d->Cin, 16));
   }
+  // (chunk, group) grid -> 1-D XCD-aware order (see BwMArgs::ngroups)
+  auto xcd_grid = [&](dim3 g) {
+    if (!g_bw_xcd_order) { a.ngroups = 0; return g; }
+    a.ngroups = (int)g.y;
+    return dim3(8u * g.y * (unsigned)cdiv((int)g.x, 8), 1, g.z);
+  };
   if (d->stride == 1 && d->kd == 3 && (a.Cin & 3) == 1 && a.Cin > 4) {
     // staged channel count 4m + 1: full groups in one launch, the one-channel group in a second, column-trimmed one
     dim3 gmain(grid.x, grid.y - 1, grid.z), gtail(grid.x, 1, grid.z);
-    conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<gmain, 256, 0, st>>>(a);
+    dim3 gm = xcd_grid(gmain);
+    conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<gm, 256, 0, st>>>(a);
     a.y0 = (int)grid.y - 1;
-    conv_bwd_weight_mfma_kernel<3, 1, 8, 2, 1><<<gtail, 256, 0, st>>>(a);
+    dim3 gt = xcd_grid(gtail);
+    conv_bwd_weight_mfma_kernel<3, 1, 8, 2, 1><<<gt, 256, 0, st>>>(a);
   } else if (d->stride == 1) {
-    if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<grid, 256, 0, st>>>(a);
-    else conv_bwd_weight_mfma_kernel<1, 1, 8, 2><<<grid, 256, 0, st>>>(a);
+    dim3 g = xcd_grid(grid);
+    if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<g, 256, 0, st>>>(a);
+    else conv_bwd_weight_mfma_kernel<1, 1, 8, 2><<<g, 256, 0, st>>>(a);
   } else if (p.nh == 2) {
-    if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 2, 2, 2><<<grid, 256, 0, st>>>(a);
-    else conv_bwd_weight_mfma_kernel<1, 2, 2, 2><<<grid, 256, 0, st>>>(a);
+    dim3 g = xcd_grid(grid);
+    if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 2, 2, 2><<<g, 256, 0, st>>>(a);
+    else conv_bwd_weight_mfma_kernel<1, 2, 2, 2><<<g, 256, 0, st>>>(a);
   } else {
-    if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 2, 2, 1><<<grid, 256, 0, st>>>(a);
-    else conv_bwd_weight_mfma_kernel<1, 2, 2, 1><<<grid, 256, 0, st>>>(a);
+    dim3 g = xcd_grid(grid);
+    if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 2, 2, 1><<<g, 256, 0, st>>>(a);
+    else conv_bwd_weight_mfma_kernel<1, 2, 2, 1><<<g, 256, 0, st>>>(a);
   }
   if (int e = dpi_check_launch("conv_bwd_weight_mfma")) return e;
   const size_t per = (size_t)d->Cout * d->Cin * d->kd * 9;

@@ -50,6 +50,9 @@ int dpi_device_info(int device, int* cus, int* lds_bytes, size_t* hbm_bytes, cha
  * rocprofv3's kernel trace records launch grids but not kernel arguments, so tools/rocpd_stats.py uses these markers to
  * attribute the dispatches that follow (in host launch order) to the layer the caller tagged; id = 1 ends a scope. */
 int dpi_profile_marker(int id, void* stream);
+/* Tuning knobs of the backward-weight MFMA launch plan (experiments / tools only): workgroups aimed at (<= 0 keeps the
+ * current value) and the XCD-aware workgroup order (0 / 1; < 0 keeps it). */
+void dpi_set_bw_tuning(int want_workgroups, int xcd_order);
 
 /* ---------------------------------------------------------------- convolution ------------------
  * Replaces nn.Conv3d / nn.Conv2d built at architectures/base.py:123,176 (k in {1,3}, stride in {1,2},
