@@ -548,20 +548,39 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
       stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
     }
     TRW();
+    // Software pipeline (as in the forward kernel): the B operands of step (hr, s + 1) and the A row of hr + 1 are requested
+    // BEFORE the 7 MFMAs of step (hr, s) and pinned there with sched_barrier — hipcc otherwise sinks every ds_read to just
+    // before its first use and the wave waits out the LDS latency once per step (MFMA pipe 58 % busy, round-2 SQ counters).
+    auto load_b = [&](float (&b)[NTQ], int hr, int s_) {
+#pragma unroll
+      for (int t = 0; t < NTQ; ++t) b[t] = lds[lbase + hr * S * G::RS + 4 * s_ * S + toff[t]];
+    };
+    float gc[KS], gn[KS], bc[NTQ], bn[NTQ];
     put_row(raw[0]);
+    get_row(gc);
+    if (1 < NR) put_row(raw[1]);                             // LDS ops of a wave execute in order: safe after the reads above
+    load_b(bc, 0, 0);
 #pragma unroll
     for (int hr = 0; hr < NR; ++hr) {
-      if (hr >= 2 && hr + 2 < NR && hr + 2 >= NPRE) load_raw(raw[hr + 2], hr + 2);
-      float g[KS];
-      get_row(g);
-      if (hr + 1 < NR) put_row(raw[hr + 1]);                 // LDS ops of a wave execute in order: safe after the reads above
+      if (hr + 3 < NR && hr + 3 >= NPRE) load_raw(raw[hr + 3], hr + 3);   // enters the row buffer 1.5 rows from now
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-#pragma unroll
-        for (int t = 0; t < NTQ; ++t) {
-          const float b = lds[lbase + hr * S * G::RS + 4 * s * S + toff[t]];
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[s], b, acc[t], 0, 0, 0);
+        if (s == KS / 2 && hr + 1 < NR) {                    // next row's A operands; then its successor may enter the row buffer
+          get_row(gn);
+          if (hr + 2 < NR) put_row(raw[hr + 2]);
         }
+        if (s + 1 < KS) load_b(bn, hr, s + 1);
+        else if (hr + 1 < NR) load_b(bn, hr + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(gc[s], bc[t], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) bc[t] = bn[t];
+      }
+      if (hr + 1 < NR) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) gc[s] = gn[s];
       }
     }
   }
