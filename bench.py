@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--mode", default="auto", choices=["auto", "eager", "graph"])
     ap.add_argument("--patches", type=int, default=8, help="c3: patches per rank taken from the queue")
-    ap.add_argument("--concurrent", type=int, default=4, help="c3: patches optimised side by side on one GPU")
+    ap.add_argument("--concurrent", type=int, default=6, help="c3: patches optimised side by side on one GPU")
     a = ap.parse_args()
     if a.steps is None:
         a.steps = 10 if a.workload == "c2" else 100
