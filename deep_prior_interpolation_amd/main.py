@@ -120,49 +120,16 @@ class Interpolator:
         self.input_ = z
 
     # ------------------------------------------------------------------------------------------
-    def _launch_noise(self):
+    def perturbed_input(self):
+        """input = z + reg_noise_std * N(0,1), fresh every iteration (main.py:148-150)."""
+        if self.args.reg_noise_std <= 0:
+            return self.input_
         out = torch.empty_like(self.input_)
         self._noise_step += 1
         _lib.check(_lib.load().dpi_noise_add(_lib.ptr(self.input_), out.numel(), float(self.args.reg_noise_std),
                                              self.noise_seed, _lib.ptr(self._noise_step), _lib.ptr(out), _lib.stream()),
                    "dpi_noise_add")
         return out
-
-    def perturbed_input(self):
-        """input = z + reg_noise_std * N(0,1), fresh every iteration (main.py:148-150)."""
-        if self.args.reg_noise_std <= 0:
-            return self.input_
-        cur = torch.cuda.current_stream(self.device)
-        pre = getattr(self, "_prefetched", None)
-        if pre is not None:                                   # produced on the noise stream during the previous iteration
-            out, ev = pre
-            self._prefetched = None
-            cur.wait_event(ev)
-            out.record_stream(cur)                            # allocated on the noise stream, consumed (and freed) here
-            return out
-        out = self._launch_noise()
-        self._noise_ev = torch.cuda.Event()
-        self._noise_ev.record(cur)
-        return out
-
-    def prefetch_perturbed_input(self):
-        """Draw the NEXT iteration's perturbed input on a stream of its own: the pass is HBM-bound (2 x 64 channels x V floats)
-        and depends only on z and the Philox step counter, so it runs beside the MFMA-bound convolutions of the current
-        iteration instead of in front of the next one.  Same counter sequence, same values as the in-line call."""
-        if self.args.reg_noise_std <= 0 or torch.cuda.is_current_stream_capturing():
-            return
-        st = getattr(self, "_noise_stream", None)
-        if st is None:
-            st = self._noise_stream = torch.cuda.Stream(device=self.device)
-        ev0 = getattr(self, "_noise_ev", None)
-        if ev0 is not None:
-            st.wait_event(ev0)                                # after the previous draw (the counter), NOT after the backward pass
-        with torch.cuda.stream(st):
-            out = self._launch_noise()
-            ev = torch.cuda.Event()
-            ev.record(st)
-        self._noise_ev = ev
-        self._prefetched = (out, ev)
 
     def _to_numpy_out(self, out_):
         """(1,1,T,X,Y) -> (T,X,Y) ; (1,C,H,W) -> (H,W,C)  (main.py:175-176)."""
@@ -181,8 +148,6 @@ class Interpolator:
         reg = self.regularization(out_, total_loss)          # None, or (weight tensor / float, reg loss) of a subclass / add-on
         if reg is None:
             total_loss.backward()
-            if net_input is None and ops.OVERLAP_WEIGHT_GRADS and self.iiter + 1 < self.args.epochs:
-                self.prefetch_perturbed_input()
             l, s, p = metrics[:3].tolist()          # one read-back for loss, snr, pcorr
             self.history.append((l, s, p))
         else:
@@ -354,9 +319,6 @@ class Interpolator:
             torch.save(self.net.state_dict(), os.path.join(self.outpath, self.image_name + "_model.pth"))
 
     def clean(self):
-        self._prefetched = None
-        if getattr(self, "_noise_stream", None) is not None:      # a draw that was prefetched but never used (early stop) may still be queued
-            torch.cuda.current_stream(self.device).wait_stream(self._noise_stream)
         self.iiter = 0
         self.loss_min = None
         self._out_best_dev = None

@@ -174,27 +174,6 @@ def conv_bwd_weight_async(d, x, chain, dy, dw):
         raw_conv_bwd_weight(d, x, chain, dy, dw)
 
 
-class _Branch:
-    """`with _Branch():` runs the enclosed launches on the side stream, ordered after everything already queued on the current
-    stream; `join_weight_grads()` (or leaving the autograd node) orders the current stream after them.  Used to run the HBM-bound
-    1x1x1 shortcut convolution of a block next to its MFMA-bound 3x3x3 chain (forward), as conv_bwd_weight_async does for the
-    weight gradients (backward).  A no-op when the overlap is off or a graph is being captured."""
-
-    def __enter__(self):
-        self.on = OVERLAP_WEIGHT_GRADS and not torch.cuda.is_current_stream_capturing()
-        if self.on:
-            side = _side_stream()
-            side.wait_stream(torch.cuda.current_stream())
-            self.ctx = torch.cuda.stream(side)
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.on:
-            self.ctx.__exit__(*exc)
-        return False
-
-
 def join_weight_grads():
     if OVERLAP_WEIGHT_GRADS and not torch.cuda.is_current_stream_capturing():
         torch.cuda.current_stream().wait_stream(_side_stream())
@@ -511,23 +490,20 @@ class Block3dFn(torch.autograd.Function):
         ch1, ch2, ch3 = CH[:c1 * 5], CH[c1 * 5:(c1 + c2) * 5], CH[(c1 + c2) * 5:]
         mi1, mi2, mi3 = (torch.empty(2 * c, **f32) for c in (c1, c2, c3))
         miA, miS, miB = (torch.empty(2 * Ct, **f32) for _ in range(3))
-        # the 1x1x1 shortcut (HBM-bound) runs on the side stream next to the 3x3x3 chain (MFMA-bound) when the overlap is on
-        dsc = make_desc(x, ws, 1)
-        S = torch.empty_like(R)
-        chS = torch.empty(Ct * 5, **f32)
-        chA = torch.empty(Ct * 5, **f32)
-        with _Branch():
-            _cba_raw(dsc, x, None, ws, bs, bns_, slope, S, miS, chS)
         _cba_raw(d1, x, None, w1, b1, bn1_, slope, r1, mi1, ch1)
         d2 = make_desc(r1, w2, 1)
         _cba_raw(d2, r1, ch1, w2, b2, bn2_, slope, r2, mi2, ch2)
         d3 = make_desc(r2, w3, 1)
         _cba_raw(d3, r2, ch2, w3, b3, bn3_, slope, r3, mi3, ch3)
         # bn1 over the virtual concat T_CH(R); chA = bn1 o T_CH
+        chA = torch.empty(Ct * 5, **f32)
         A = blk.bn1
         raw_bn_stats_finalize(R, CH, Ct, V, gA, eA, 1.0, A.running_mean, A.running_var, A.num_batches_tracked, miA, chA,
                               compose=True)
-        join_weight_grads()
+        dsc = make_desc(x, ws, 1)
+        S = torch.empty_like(R)
+        chS = torch.empty(Ct * 5, **f32)
+        _cba_raw(dsc, x, None, ws, bs, bns_, slope, S, miS, chS)
         # residual join + statistics of act(t) for bn2
         t = torch.empty_like(R)
         nblk = L.dpi_stat_blocks(Ct, V)
@@ -610,10 +586,8 @@ class ResPath3dFn(torch.autograd.Function):
         r1 = torch.empty_like(r3)
         mi3, mi1, miB = (torch.empty(2 * Ct, **f32) for _ in range(3))
         ch3, ch1, chB = (torch.empty(5 * Ct, **f32) for _ in range(3))
-        with _Branch():
-            _cba_raw(d1, x, None, w1, b1, bn1_, slope, r1, mi1, ch1)
         _cba_raw(d3, x, None, w3, b3, bn3_, slope, r3, mi3, ch3)
-        join_weight_grads()
+        _cba_raw(d1, x, None, w1, b1, bn1_, slope, r1, mi1, ch1)
         t = torch.empty_like(r3)
         nblk = L.dpi_stat_blocks(Ct, V)
         part = torch.empty(nblk * Ct * 2, dtype=torch.float64, device=x.device)
@@ -680,13 +654,8 @@ class SkipJoinFn(torch.autograd.Function):
         r1 = torch.empty_like(r3)
         mi3, mi1, miB = (torch.empty(2 * Cs, **f32) for _ in range(3))
         ch3, ch1, chB = (torch.empty(5 * Cs, **f32) for _ in range(3))
-        cat = torch.empty(_like_spatial(x, Cs + Cd, Do, Ho, Wo), **f32)
-        with _Branch():        # HBM-bound work next to the 3x3x3 conv: the 1x1x1 branch and the up-sampling of the deep branch
-            _cba_raw(d1, x, None, w1, b1, bn1_, slope, r1, mi1, ch1)
-            check(L.dpi_upsample2x_fwd(ptr(deep), None, Cd, Dd, Hd, Wd, Do, Ho, Wo, int(linear), ptr(cat[:, Cs:]), stream()),
-                  "dpi_upsample2x_fwd")
         _cba_raw(d3, x, None, w3, b3, bn3_, slope, r3, mi3, ch3)
-        join_weight_grads()
+        _cba_raw(d1, x, None, w1, b1, bn1_, slope, r1, mi1, ch1)
         t = torch.empty_like(r3)
         nblk = L.dpi_stat_blocks(Cs, V)
         part = torch.empty(nblk * Cs * 2, dtype=torch.float64, device=x.device)
@@ -695,7 +664,10 @@ class SkipJoinFn(torch.autograd.Function):
         B = rp.bn
         raw_bn_finalize(part, nblk, Cs, V, gB, eB, slope, B.running_mean, B.running_var, B.num_batches_tracked, miB, chB,
                         act_first=1)
+        cat = torch.empty(_like_spatial(x, Cs + Cd, Do, Ho, Wo), **f32)
         raw_chain_apply(t, chB, Cs, V, cat[:, :Cs])
+        check(L.dpi_upsample2x_fwd(ptr(deep), None, Cd, Dd, Hd, Wd, Do, Ho, Wo, int(linear), ptr(cat[:, Cs:]), stream()),
+              "dpi_upsample2x_fwd")
         ctx.save_for_backward(x, r3, r1, t, mi3, mi1, miB, *[q for q in p if q is not None])
         ctx.none_mask = [q is None for q in p]
         ctx.descs = (d3, d1)

@@ -180,30 +180,6 @@ def test_graph_mode_matches_eager(golden):
         np.testing.assert_array_equal(res["graph"][4][k], v, err_msg=k)
 
 
-def test_stream_overlap_modes_are_bit_identical(golden, monkeypatch):
-    """The eager loop with the overlaps on (weight gradients and the 1x1x1 / up-sampling branches on the side stream, the next
-    iteration's perturbed input drawn on its own stream) reproduces the serial loop bit for bit: same kernels, same operands,
-    same Philox counter sequence — only the stream they are queued on differs."""
-    from deep_prior_interpolation_amd import ops
-    g = golden("net_mulresunet3d_tiny_trilinear_mae")
-    res = {}
-    monkeypatch.setattr(ops, "set_weight_grad_overlap", lambda on: None)
-    for overlap in (False, True):
-        monkeypatch.setattr(ops, "OVERLAP_WEIGHT_GRADS", overlap)
-        T, a = _interpolator(g, 10)
-        T.noise_seed = 11
-        T.optimize(verbose=False, mode="eager")
-        torch.cuda.synchronize()
-        res[overlap] = (np.array(T.history.loss), np.array(T.history.snr), T.out_best.copy(),
-                        {k: v.detach().cpu().numpy().copy() for k, v in T.net.state_dict().items()})
-        assert (getattr(T, "_noise_stream", None) is not None) == overlap
-    np.testing.assert_array_equal(res[True][0], res[False][0])
-    np.testing.assert_array_equal(res[True][1], res[False][1])
-    np.testing.assert_array_equal(res[True][2], res[False][2])
-    for k, v in res[False][3].items():
-        np.testing.assert_array_equal(res[True][3][k], v, err_msg=k)
-
-
 def test_graph_mode_device_early_stop_and_plateau(golden):
     """Device-side ReduceLROnPlateau and EarlyStopping follow the host implementations of the eager loop."""
     g = golden("net_mulresunet3d_tiny_nearest_mse")
