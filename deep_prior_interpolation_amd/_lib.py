@@ -17,7 +17,7 @@ class DpiError(RuntimeError):
 
 class ConvDesc(C.Structure):
     _fields_ = [("Cin", C.c_int), ("Cout", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
-                ("k", C.c_int), ("kd", C.c_int), ("stride", C.c_int)]
+                ("k", C.c_int), ("kd", C.c_int), ("stride", C.c_int), ("precision", C.c_int)]
 
 
 class AdamTensor(C.Structure):

@@ -1,0 +1,288 @@
+// bf16-MFMA stencil convolution (k = 3, stride 1; forward and backward-data) for gfx950 — the mixed-precision mode of
+// BASELINE configs[4] ("bf16 activations + fp32 master weights"): operands are rounded to bf16 (round-to-nearest-even) while
+// they are staged into LDS, products are exact in fp32 and accumulate in fp32 (v_mfma_f32_16x16x32_bf16), tensors in HBM and
+// the master weights stay fp32, BatchNorm statistics / Adam stay fp32.  16x the matrix rate of the fp32 MFMA path
+// (conv_mfma.hip), so the kernel is bound by its LDS operand reads and, beyond that, by HBM.
+//
+// Implicit GEMM per output tile:   D[co 16][vox 16] += A[co 16][K 32] * B[K 32][vox 16]
+//     K block = 8 input channels x 4 taps (tap = 4 g + lane>>4, g = 0 .. ceil(TAPS / 4) - 1): a small channel count still fills K,
+//     and one staged group of 8 channels serves all 27 taps.
+//     B = halo tile in LDS as [position][8 channels] bf16 (16 B per position): lane (vox = l & 15, tap slot = l >> 4) reads ONE
+//         ds_read_b128 at position(vox) + offset(tap) — 16 consecutive positions per 16-lane group, conflict-free.
+//     A = weights of the 8-channel group, converted to bf16 by the workgroup once per group and shared through LDS as ready-made
+//         fragments [g][lane][8] (the torch layout [Cout][Cin][27] would cost every lane 8 strided loads per fragment).
+// Workgroup = 4 waves = output tile 4x4x32 (or the small 1x8x16/32 variants for coarse levels), as in conv_mfma.hip; D layout,
+// epilogue (bias, BatchNorm {sum, sum^2} partials, gradient fan-in) are those of the fp32 kernel.
+#include "common.h"
+
+void dpi_conv_out_dims(const dpi_conv_desc* d, int* Do, int* Ho, int* Wo);
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct BArgs {
+  const float* __restrict__ x;
+  const float* __restrict__ chain;
+  const float* __restrict__ w;
+  const float* __restrict__ bias;
+  float* __restrict__ y;
+  double* __restrict__ partials;
+  int Cin, Cout;
+  int D, H, W;
+  int ntd, nth, ntw;
+  long w_out_stride, w_in_stride;
+  int accumulate;
+};
+
+template <int KD, int NR, int NH>
+struct GeoB {
+  static constexpr bool SLICES = (KD == 3 && NR >= 4);          // waves split depth; otherwise they split rows
+  static constexpr int TZ = SLICES ? 4 : 1;                      // output tile
+  static constexpr int TY = SLICES ? NR : 4 * NR;
+  static constexpr int TW = 16 * NH;
+  static constexpr int ID = TZ - 1 + KD;                         // input (halo) tile, positions stored densely [ID][IH][IW]
+  static constexpr int IH = TY + 2;
+  static constexpr int IW = TW + 2;
+  static constexpr int TILE = ID * IH * IW;
+  static constexpr int E = (TILE + 255) / 256;
+  static constexpr int TAPS = KD * 9;
+  static constexpr int NTG = (TAPS + 3) / 4;                     // tap groups of 4 (7 for 3-D: 27 of 28 K slots used)
+  static constexpr int WE = (NTG * 64 * 8 + 255) / 256;          // weight elements each thread converts per channel group
+};
+
+// round-to-nearest-even fp32 -> bf16 (the rounding torch.Tensor.bfloat16() applies), two values packed into one dword
+__device__ __forceinline__ unsigned bf16_bits(float f) {
+  unsigned u = __builtin_bit_cast(unsigned, f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) { return bf16_bits(lo) | (bf16_bits(hi) << 16); }
+
+__device__ __forceinline__ int xcd_tile_b(int bid, int ntiles) {        // contiguous tile range per XCD (see conv_mfma.hip)
+  const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, i = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+template <int KD, int NR, int NH, bool FLIP>
+__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(BArgs a) {
+  using G = GeoB<KD, NR, NH>;
+  constexpr int TAPS = G::TAPS, NTG = G::NTG, PD = (KD - 1) / 2, NT = NR * NH;
+  __shared__ __attribute__((aligned(16))) unsigned xl[G::TILE * 4];        // [position][8 bf16]
+  __shared__ __attribute__((aligned(16))) unsigned short wl[NTG * 64 * 8];  // [g][lane][8 bf16]: A fragments
+  __shared__ double red[4][16][2];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int n0 = blockIdx.y * 16;
+  const size_t V = (size_t)a.D * a.H * a.W;
+  const int ntiles = a.ntd * a.nth * a.ntw;
+  const int Do = a.D, Ho = a.H, Wo = a.W;                      // stride 1, 'same' padding
+  const size_t Vo = V;
+
+  const int tile_id = xcd_tile_b(blockIdx.x, ntiles);
+  int od0, oh0, ow0;
+  {
+    int bt = tile_id;
+    const int tw_i = bt % a.ntw; bt /= a.ntw;
+    const int th_i = bt % a.nth; bt /= a.nth;
+    od0 = bt * G::TZ; oh0 = th_i * G::TY; ow0 = tw_i * G::TW;
+  }
+  const int wz = G::SLICES ? wid : 0, wh = G::SLICES ? 0 : wid * NR;
+
+  // halo-tile slots of this thread: position idx = tid + 256 e  <->  (dz, hy, col), and the global voxel offset (or -1 = padding)
+  int goff[G::E];
+#pragma unroll
+  for (int e = 0; e < G::E; ++e) {
+    const int idx = tid + e * 256;
+    const int col = idx % G::IW, row = idx / G::IW;
+    const int hy = row % G::IH, dz = row / G::IH;
+    const int gd = od0 - PD + dz, gh = oh0 - 1 + hy, gw = ow0 - 1 + col;
+    const bool ok = idx < G::TILE && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+    goff[e] = ok ? (gd * a.H + gh) * a.W + gw : -1;
+  }
+  // per-lane tap offsets (in positions) of the NTG tap groups; K slot lk of group g is tap 4 g + lk (clamped: its weights are 0)
+  int toff[NTG];
+#pragma unroll
+  for (int g = 0; g < NTG; ++g) {
+    const int t = min(4 * g + lk, TAPS - 1);
+    const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+    toff[g] = (kd * G::IH + kh) * G::IW + kw;
+  }
+  const int pbase = (wz * G::IH + wh) * G::IW + lj;            // position of output voxel (row 0, column block 0) at tap (0,0,0)
+
+  float sr[8][G::E];                                           // next channel group, raw fp32, in flight
+  float wq[G::WE];                                             // next channel group's weights of this thread
+  auto load_x = [&](int c0) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int ci = min(c0 + c, a.Cin - 1);                   // channels past Cin: their weights are zero
+      const __amdgpu_buffer_rsrc_t r = dpi_buffer(a.x + (size_t)ci * V, V * sizeof(float));
+#pragma unroll
+      for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_buffer_load(r, goff[e] * 4);
+    }
+  };
+  auto load_w = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < G::WE; ++j) {
+      const int q = tid + j * 256;                             // element (g, lane64, i)
+      const int i = q & 7, l64 = (q >> 3) & 63, g = q >> 9;
+      const int co = n0 + (l64 & 15), tap = 4 * g + (l64 >> 4), ci = c0 + i;
+      const bool ok = q < NTG * 512 && co < a.Cout && ci < a.Cin && tap < TAPS;
+      const float v = a.w[(ok ? co : 0) * a.w_out_stride + (ok ? ci : 0) * a.w_in_stride + (ok ? (FLIP ? TAPS - 1 - tap : tap) : 0)];
+      wq[j] = ok ? v : 0.f;
+    }
+  };
+  load_x(0);
+  load_w(0);
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (a.accumulate) {                                          // gradient fan-in: start from the destination
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = n0 + 4 * lk + r;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
+        if (co < a.Cout && od < Do && oh < Ho && ow < Wo) acc[t][r] = a.y[(size_t)co * Vo + ((size_t)od * Ho + oh) * Wo + ow];
+      }
+    }
+  }
+
+  for (int c0 = 0; c0 < a.Cin; c0 += 8) {
+    __syncthreads();                                           // everyone is done reading the previous group
+    // registers -> LDS: chain (BN + LeakyReLU of the producer) on in-volume samples, round to bf16, 8 channels per position
+    {
+      if (a.chain) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const Chain ch = load_chain(a.chain, min(c0 + c, a.Cin - 1));
+#pragma unroll
+          for (int e = 0; e < G::E; ++e) sr[c][e] = goff[e] >= 0 ? apply_chain(ch, sr[c][e]) : sr[c][e];   // zero padding stays zero
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < G::E; ++e) {
+        const int idx = tid + e * 256;
+        if ((e + 1) * 256 <= G::TILE || idx < G::TILE)
+          *reinterpret_cast<u32x4*>(xl + idx * 4) = (u32x4){pack_bf16(sr[0][e], sr[1][e]), pack_bf16(sr[2][e], sr[3][e]),
+                                                            pack_bf16(sr[4][e], sr[5][e]), pack_bf16(sr[6][e], sr[7][e])};
+      }
+#pragma unroll
+      for (int j = 0; j < G::WE; ++j) {
+        const int q = tid + j * 256;
+        if ((j + 1) * 256 <= NTG * 512 || q < NTG * 512) wl[q] = (unsigned short)bf16_bits(wq[j]);
+      }
+    }
+    __syncthreads();
+    if (c0 + 8 < a.Cin) { load_x(c0 + 8); load_w(c0 + 8); }   // next group behind this group's MFMAs
+
+    bf16x8 af[NTG];
+#pragma unroll
+    for (int g = 0; g < NTG; ++g) af[g] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wl + (g * 64 + lane) * 8));
+#pragma unroll
+    for (int g = 0; g < NTG; ++g) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {                           // consecutive MFMAs go to different accumulators
+        const int p = pbase + toff[g] + (t / NH) * G::IW + (t % NH) * 16;
+        const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xl + p * 4));
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g], b, acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: D row = co (4*lk + r), D col = voxel lj (same layout as the fp32 16x16x4 MFMA) ---------------------------
+  const bool interior = od0 + G::TZ <= Do && oh0 + G::TY <= Ho && ow0 + G::TW <= Wo && n0 + 16 <= a.Cout;
+  const int vbase = ((od0 + wz) * Ho + oh0 + wh) * Wo + ow0 + lj;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = n0 + 4 * lk + r;
+    const bool cok = co < a.Cout;
+    const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
+    float* __restrict__ yc = a.y + (size_t)(cok ? co : 0) * Vo + vbase;
+    double s = 0.0, q = 0.0;
+    if (interior) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float v = acc[t][r] + bv;
+        yc[(t / NH) * Wo + (t % NH) * 16] = v;
+        if (a.partials) { s += v; q += (double)v * v; }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
+        if (cok && od < Do && oh < Ho && ow < Wo) {
+          const float v = acc[t][r] + bv;
+          yc[(t / NH) * Wo + (t % NH) * 16] = v;
+          s += v;
+          q += (double)v * v;
+        }
+      }
+    }
+    if (a.partials) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+      if (lj == 0) { red[wid][4 * lk + r][0] = s; red[wid][4 * lk + r][1] = q; }
+    }
+  }
+  if (a.partials) {
+    __syncthreads();
+    if (tid < 32) {
+      const int c = tid >> 1, which = tid & 1;
+      const double rsum = red[0][c][which] + red[1][c][which] + red[2][c][which] + red[3][c][which];
+      if (n0 + c < a.Cout) a.partials[((size_t)tile_id * a.Cout + n0 + c) * 2 + which] = rsum;
+    }
+  }
+}
+
+}  // namespace
+
+// tile variant: the 4x4x32 tile (2-D: 1x16x32) while it still gives >= 512 workgroups, else row-band tiles of one depth slice.
+// (The 4x8x32 tile of the fp32 kernel needs 64 prefetch + 64 accumulator registers here and spills.)
+static void bf16_variant(const dpi_conv_desc* d, int cout, int* nr, int* nh) {
+  const int tz = d->kd == 3 ? 4 : 1, ty = d->kd == 3 ? 4 : 16;
+  const long nb = (long)cdiv(d->D, tz) * cdiv(d->H, ty) * cdiv(d->W, 32) * cdiv(cout, 16);
+  if (nb >= 512) { *nr = 4; *nh = 2; }
+  else { *nr = 2; *nh = d->W > 16 ? 2 : 1; }
+}
+static int bf16_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth, int* ntw) {
+  const bool slices = d->kd == 3 && nr >= 4;
+  const int tz = slices ? 4 : 1, ty = slices ? nr : 4 * nr;
+  *ntd = cdiv(d->D, tz); *nth = cdiv(d->H, ty); *ntw = cdiv(d->W, 16 * nh);
+  return *ntd * *nth * *ntw;
+}
+
+bool dpi_conv_bf16_usable(const dpi_conv_desc* d) { return d->precision == 1 && d->k == 3 && d->stride == 1; }
+
+int dpi_conv_bf16_stat_blocks(const dpi_conv_desc* d) {
+  int nr, nh, a, b, c;
+  bf16_variant(d, d->Cout, &nr, &nh);
+  return bf16_tiles(d, nr, nh, &a, &b, &c);
+}
+
+template <int KD, bool FLIP>
+static void launch_bf16(const BArgs& a, int nr, int nh, dim3 grid, hipStream_t st) {
+  if (nr == 4) conv_bf16_kernel<KD, 4, 2, FLIP><<<grid, 256, 0, st>>>(a);
+  else if (nh == 2) conv_bf16_kernel<KD, 2, 2, FLIP><<<grid, 256, 0, st>>>(a);
+  else conv_bf16_kernel<KD, 2, 1, FLIP><<<grid, 256, 0, st>>>(a);
+}
+
+int dpi_conv_bf16_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
+                      double* partials, bool flip, int accumulate, hipStream_t st) {
+  const int taps = d->kd * 9;
+  const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
+  const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
+  int nr, nh;
+  bf16_variant(d, cout, &nr, &nh);
+  BArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, accumulate};
+  const int ntiles = bf16_tiles(d, nr, nh, &a.ntd, &a.nth, &a.ntw);
+  dim3 grid(ntiles, cdiv(cout, 16));
+  if (d->kd == 3) { if (flip) launch_bf16<3, true>(a, nr, nh, grid, st); else launch_bf16<3, false>(a, nr, nh, grid, st); }
+  else { if (flip) launch_bf16<1, true>(a, nr, nh, grid, st); else launch_bf16<1, false>(a, nr, nh, grid, st); }
+  return dpi_check_launch("conv_bf16_mfma");
+}

@@ -43,13 +43,25 @@ def conv_out(n, k, s):
     return (n + 2 * ((k - 1) // 2) - k) // s + 1
 
 
+# 0: fp32 arithmetic (the reference's).  1: BASELINE configs[4] mixed precision — 3x3(x3) stride-1 convolutions feed bf16-rounded
+# operands to the matrix cores with fp32 accumulation; tensors, master weights, BatchNorm statistics and Adam stay fp32.
+PRECISION = 1 if os.environ.get("DPI_PRECISION", "fp32") == "bf16" else 0
+
+
+def set_precision(name):
+    global PRECISION
+    if name not in ("fp32", "bf16"):
+        raise ValueError("precision must be 'fp32' or 'bf16'")
+    PRECISION = 1 if name == "bf16" else 0
+
+
 def make_desc(x, w, stride):
     Cin, D, H, W = _dims(x)
     k = w.shape[-1]
     kd = w.shape[2] if w.ndim == 5 else 1
     if w.shape[1] != Cin:
         raise _lib.DpiError("conv: weight expects %d input channels, tensor has %d" % (w.shape[1], Cin))
-    return ConvDesc(Cin, w.shape[0], D, H, W, k, kd, int(stride))
+    return ConvDesc(Cin, w.shape[0], D, H, W, k, kd, int(stride), PRECISION)
 
 
 def desc_out_dims(d):

@@ -65,6 +65,10 @@ typedef struct {
   int D, H, W;      /* input spatial size */
   int k, kd;        /* kernel extent in H/W and in D */
   int stride;       /* 1 or 2 (applies to D only when kd > 1) */
+  /* 0 (default): fp32 operands, the reference's arithmetic.  1: mixed precision of BASELINE configs[4] — the operands of 3x3(x3)
+   * stride-1 convolutions (forward, backward-data, backward-weight) are rounded to bf16 on their way into the matrix cores
+   * (v_mfma_f32_16x16x32_bf16, fp32 accumulate); tensors in HBM, master weights, BatchNorm statistics and Adam stay fp32. */
+  int precision;
 } dpi_conv_desc;
 
 /* number of stat-partial blocks dpi_conv_fwd writes for this problem (0 if desc invalid) */

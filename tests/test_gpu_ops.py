@@ -387,3 +387,79 @@ def test_channel_dropout_semantics(ops):
     y.sum().backward()
     np.testing.assert_allclose(x.grad[0, :, 0, 0, 0].cpu().numpy(), r, atol=1e-6)
     assert hnn.Dropout(0.0)(x) is x
+
+
+# ---- BASELINE configs[4] mixed precision: bf16 operands, fp32 accumulate (csrc/conv_bf16_mfma.hip) ------------------------------
+BF16_CASES = [(25, 16, (12, 9, 40), 3), (64, 4, (8, 12, 36), 3), (4, 8, (9, 17, 33), 3), (8, 13, (8, 8, 32), 3), (25, 1, (8, 16, 32), 3),
+              (67, 4, (6, 10, 34), 3), (35, 71, (8, 8, 8), 3), (71, 142, (4, 4, 4), 3), (17, 26, (6, 6, 6), 3), (105, 64, (4, 8, 16), 3),
+              (9, 20, (16, 20, 70), 3), (16, 16, (3, 5, 17), 3), (5, 3, (1, 1, 1), 3), (51, 32, (32, 32, 64), 3)]
+
+
+@pytest.mark.parametrize("cin,cout,shape,k", BF16_CASES)
+def test_conv_bf16_mode_vs_oracle(ops, cin, cout, shape, k, monkeypatch):
+    """precision = 1: operands rounded to bf16 (RNE) on the way into v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+    (1) With bf16-REPRESENTABLE inputs the rounding is the identity, so the kernel must match the fp64 oracle as tightly as the
+        fp32 path (2e-6): this pins the tiling, the K = 8 channels x 4 taps packing and the fragment layouts.
+    (2) With arbitrary fp32 inputs the result must equal the oracle applied to the bf16-rounded operands (2e-6) and sit within
+        the bf16 rounding envelope of the exact result (5e-3 norm-wise).  Backward-data runs the same kernel (flipped weights)."""
+    monkeypatch.setattr(ops, "PRECISION", 1)
+    gen = torch.Generator().manual_seed(cin * 1000 + cout)
+    x = torch.randn((1, cin) + shape, generator=gen)
+    w = torch.randn((cout, cin, k, k, k), generator=gen) * (1.0 / np.sqrt(cin * k ** 3))
+    b = torch.randn(cout, generator=gen)
+    dy = torch.randn((1, cout) + shape, generator=gen)
+    for rounded in (True, False):
+        xq, wq, dyq = (t.bfloat16().float() for t in (x, w, dy))
+        xi, wi, dyi = (xq, wq, dyq) if rounded else (x, w, dy)
+        xr, wr = xq.double().requires_grad_(True), wq.double()
+        yr = O.conv_nd(xr, wr, b.double(), 1)
+        yr.backward(dyq.double())
+        xg, wg = xi.to(DEV).requires_grad_(True), wi.to(DEV)
+        y = ops.conv(xg, wg, b.to(DEV), 1)
+        assert rel(y, yr) < 2e-6, rounded
+        d = ops.make_desc(xg, wg, 1)
+        dx = torch.empty_like(xg)
+        ops.raw_conv_bwd_data(d, dyi.to(DEV), wg, dx)
+        assert rel(dx, xr.grad) < 2e-6, rounded
+        if not rounded:
+            y_exact = O.conv_nd(x.double(), w.double(), b.double(), 1)
+            assert rel(y, y_exact) < 5e-3
+    # accumulate and the fused chain / statistics epilogue go through the same entry points
+    base = torch.randn(x.shape, generator=gen).to(DEV)
+    acc = base.clone()
+    ops.raw_conv_bwd_data(d, dy.to(DEV), wg, acc, accumulate=True)
+    plain = torch.empty_like(acc)
+    ops.raw_conv_bwd_data(d, dy.to(DEV), wg, plain)
+    assert rel(acc, base + plain) < 1e-6
+
+
+def test_conv_bf16_mode_chain_and_stats(ops, monkeypatch):
+    import ctypes as C
+    from deep_prior_interpolation_amd import _lib
+    monkeypatch.setattr(ops, "PRECISION", 1)
+    L = _lib.load()
+    gen = torch.Generator().manual_seed(5)
+    cin, cout, shape = 13, 9, (7, 12, 37)
+    x = torch.randn((1, cin) + shape, generator=gen)
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=gen) * 0.1).bfloat16().float()
+    b = torch.randn(cout, generator=gen)
+    chain = torch.stack([1.0 + 0.3 * torch.randn(cin, generator=gen), 0.2 * torch.randn(cin, generator=gen), torch.full((cin,), 0.2),
+                         1.0 + 0.3 * torch.randn(cin, generator=gen), 0.2 * torch.randn(cin, generator=gen)], dim=1).contiguous()
+    v = chain[:, 0].view(1, -1, 1, 1, 1) * x + chain[:, 1].view(1, -1, 1, 1, 1)
+    tx = chain[:, 3].view(1, -1, 1, 1, 1) * torch.where(v > 0, v, 0.2 * v) + chain[:, 4].view(1, -1, 1, 1, 1)
+    # the kernel applies the chain in fp32 (fmaf) and then rounds to bf16
+    xg, wg, bg, cg = x.to(DEV), w.to(DEV), b.to(DEV), chain.to(DEV)
+    d = ops.make_desc(xg, wg, 1)
+    y = torch.empty((1, cout) + shape, device=DEV)
+    nblk = L.dpi_conv_fwd_stat_blocks(C.byref(d))
+    part = torch.empty(nblk * cout * 2, dtype=torch.float64, device=DEV)
+    ops.raw_conv_fwd(d, xg, cg, wg, bg, y, part)
+    txg = torch.empty_like(xg)
+    ops.raw_chain_apply(xg, cg, cin, xg.numel() // cin, txg)
+    yr = O.conv_nd(txg.cpu().bfloat16().double(), w.double(), b.double(), 1)
+    assert rel(y, yr) < 2e-6
+    assert rel(txg, tx) < 1e-6
+    p = part.view(nblk, cout, 2).sum(0).cpu().numpy()
+    yn = y.double().cpu().numpy()[0]
+    np.testing.assert_allclose(p[:, 0], yn.reshape(cout, -1).sum(1), rtol=1e-9, atol=1e-7)
+    np.testing.assert_allclose(p[:, 1], (yn.reshape(cout, -1) ** 2).sum(1), rtol=1e-9)
