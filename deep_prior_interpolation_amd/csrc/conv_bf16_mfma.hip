@@ -50,8 +50,7 @@ struct GeoB {
   static constexpr int E = (TILE + 255) / 256;
   static constexpr int TAPS = KD * 9;
   static constexpr int NTG = (TAPS + 3) / 4;                     // tap groups of 4 (7 for 3-D: 27 of 28 K slots used)
-  static constexpr int WN = 16 * 8 * TAPS;                       // weights of one (16 output channels x 8 input channels) group
-  static constexpr int WE = (WN + 255) / 256;                    // ... per thread
+  static constexpr int WE = (NTG * 64 * 8 + 255) / 256;          // weight elements each thread converts per channel group
 };
 
 // round-to-nearest-even fp32 -> bf16 (the rounding torch.Tensor.bfloat16() applies), two values packed into one dword
@@ -125,27 +124,17 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(BArgs a) {
       for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_buffer_load(r, goff[e] * 4);
     }
   };
-  // Weights of the group in MEMORY order (coalesced: the 8 x TAPS block of one output channel is contiguous in torch's
-  // [Cout][Cin][TAPS] layout; for the flipped backward-data view the 16 x TAPS block of one input channel is), scattered into
-  // fragment order [g][lane = (tap & 3) * 16 + co][ci] when they are written to LDS.  (Fragment-order loads — 8 floats 108 B
-  // apart per lane — kept the address unit busy twice as long as the MFMAs.)
-  auto w_elem = [&](int q, int& co_l, int& ci_l, int& tap) {
-    if (FLIP) { ci_l = q / (16 * TAPS); const int r = q % (16 * TAPS); co_l = r / TAPS; tap = r % TAPS; }
-    else { co_l = q / (8 * TAPS); const int r = q % (8 * TAPS); ci_l = r / TAPS; tap = r % TAPS; }
-  };
   auto load_w = [&](int c0) {
 #pragma unroll
     for (int j = 0; j < G::WE; ++j) {
-      int co_l, ci_l, tap;
-      w_elem(tid + j * 256, co_l, ci_l, tap);
-      const int co = n0 + co_l, ci = c0 + ci_l;
-      const bool ok = tid + j * 256 < G::WN && co < a.Cout && ci < a.Cin;
+      const int q = tid + j * 256;                             // element (g, lane64, i)
+      const int i = q & 7, l64 = (q >> 3) & 63, g = q >> 9;
+      const int co = n0 + (l64 & 15), tap = 4 * g + (l64 >> 4), ci = c0 + i;
+      const bool ok = q < NTG * 512 && co < a.Cout && ci < a.Cin && tap < TAPS;
       const float v = a.w[(ok ? co : 0) * a.w_out_stride + (ok ? ci : 0) * a.w_in_stride + (ok ? (FLIP ? TAPS - 1 - tap : tap) : 0)];
       wq[j] = ok ? v : 0.f;
     }
   };
-  // K slots past the last tap (tap 27 of the 28 in 3-D) are never written below: zero them once
-  for (int q = tid; q < (NTG * 4 - TAPS) * 16 * 8; q += 256) wl[(TAPS * 16) * 8 + q] = 0;
   load_x(0);
   load_w(0);
 
@@ -185,9 +174,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(BArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < G::WE; ++j) {
-        int co_l, ci_l, tap;
-        w_elem(tid + j * 256, co_l, ci_l, tap);
-        if ((j + 1) * 256 <= G::WN || tid + j * 256 < G::WN) wl[(tap * 16 + co_l) * 8 + ci_l] = (unsigned short)bf16_bits(wq[j]);
+        const int q = tid + j * 256;
+        if ((j + 1) * 256 <= NTG * 512 || q < NTG * 512) wl[q] = (unsigned short)bf16_bits(wq[j]);
       }
     }
     __syncthreads();
