@@ -35,6 +35,7 @@ struct BArgs {
   int ntd, nth, ntw;
   long w_out_stride, w_in_stride;
   int accumulate;
+  int debug;     // tuning experiments only (dpi_set_bf16_debug): 1 skip the MFMA phase, 2 skip the global loads, 4 skip the LDS stores
 };
 
 template <int KD, int NR, int NH>
@@ -135,8 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(BArgs a) {
       wq[j] = ok ? v : 0.f;
     }
   };
-  load_x(0);
-  load_w(0);
+  if (!(a.debug & 2)) { load_x(0); load_w(0); }
 
   f32x4 acc[NT];
 #pragma unroll
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(BArgs a) {
   for (int c0 = 0; c0 < a.Cin; c0 += 8) {
     __syncthreads();                                           // everyone is done reading the previous group
     // registers -> LDS: chain (BN + LeakyReLU of the producer) on in-volume samples, round to bf16, 8 channels per position
-    {
+    if (!(a.debug & 4)) {
       if (a.chain) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(BArgs a) {
       }
     }
     __syncthreads();
-    if (c0 + 8 < a.Cin) { load_x(c0 + 8); load_w(c0 + 8); }   // next group behind this group's MFMAs
+    if (c0 + 8 < a.Cin && !(a.debug & 2)) { load_x(c0 + 8); load_w(c0 + 8); }   // next group behind this group's MFMAs
+    if (a.debug & 1) continue;
 
     bf16x8 af[NTG];
 #pragma unroll
@@ -257,6 +258,9 @@ static int bf16_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth
   return *ntd * *nth * *ntw;
 }
 
+static int g_bf16_debug = 0;
+extern "C" void dpi_set_bf16_debug(int flags) { g_bf16_debug = flags; }
+
 bool dpi_conv_bf16_usable(const dpi_conv_desc* d) { return d->precision == 1 && d->k == 3 && d->stride == 1; }
 
 int dpi_conv_bf16_stat_blocks(const dpi_conv_desc* d) {
@@ -279,7 +283,7 @@ int dpi_conv_bf16_run(const dpi_conv_desc* d, const float* x, const float* chain
   const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
   int nr, nh;
   bf16_variant(d, cout, &nr, &nh);
-  BArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, accumulate};
+  BArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, accumulate, g_bf16_debug};
   const int ntiles = bf16_tiles(d, nr, nh, &a.ntd, &a.nth, &a.ntw);
   dim3 grid(ntiles, cdiv(cout, 16));
   if (d->kd == 3) { if (flip) launch_bf16<3, true>(a, nr, nh, grid, st); else launch_bf16<3, false>(a, nr, nh, grid, st); }

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--bw-mfma-min-cout", type=int, default=None)
     ap.add_argument("--which", nargs="*", default=["fwd", "bwd_data", "bwd_weight"])
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--bf16-debug", type=int, default=0)
     ap.add_argument("--bw-want", type=int, default=0, help="backward-weight plan: workgroups aimed at (dpi_set_bw_tuning)")
     ap.add_argument("--bw-xcd", type=int, default=-1, help="backward-weight plan: XCD-aware workgroup order 0/1")
     a = ap.parse_args()
@@ -43,6 +44,9 @@ def main():
         L.dpi_set_bwd_weight_mfma_min_cout(a.bw_mfma_min_cout)
     L.dpi_set_bw_tuning(a.bw_want, a.bw_xcd)
     ops.set_precision(a.precision)
+    if a.bf16_debug:
+        L.dpi_set_bf16_debug.argtypes = [C.c_int]
+        L.dpi_set_bf16_debug(a.bf16_debug)
     dev = "cuda"
     print("%-16s %-10s %10s %9s %8s" % ("case", "kernel", "ms", "TFLOP/s", "GB/s(alg)"))
     for name in a.cases:
