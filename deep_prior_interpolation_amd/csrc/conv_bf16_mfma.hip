@@ -79,26 +79,17 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(BArgs a) {
   const int lk = lane >> 4, lj = lane & 15;
   const int n0 = blockIdx.y * 16;
   const size_t V = (size_t)a.D * a.H * a.W;
-  const int ntiles = (int)gridDim.x;                           // padded to whole 4x4x4 blocks of tiles (bf16_tiles)
+  const int ntiles = a.ntd * a.nth * a.ntw;
   const int Do = a.D, Ho = a.H, Wo = a.W;                      // stride 1, 'same' padding
   const size_t Vo = V;
 
-  // Tile order: the launch is padded to whole 4x4x4 blocks of tiles; an XCD's contiguous range walks block after block, so the
-  // ~64 tiles in flight on an XCD are mutual neighbours and their halo planes / rows / columns (2.4x the tile's own voxels at
-  // 4x4x32) are fetched from HBM once and then served by that XCD's L2.  Measured on 25 -> 16 @256x128x128 in plain (d, h, w)
-  // order: the staging loads alone took 240 us = 1.28 GB at HBM speed, i.e. every halo re-read went to memory.
   const int tile_id = xcd_tile_b(blockIdx.x, ntiles);
   int od0, oh0, ow0;
   {
-    const int nbx = (a.ntw + 3) >> 2, nby = (a.nth + 3) >> 2;
-    const int blk = tile_id >> 6, in = tile_id & 63;
-    const int bx = blk % nbx, by = (blk / nbx) % nby, bz = blk / (nbx * nby);
-    const int tw_i = bx * 4 + (in & 3), th_i = by * 4 + ((in >> 2) & 3), td_i = bz * 4 + (in >> 4);
-    if (tw_i >= a.ntw || th_i >= a.nth || td_i >= a.ntd) {     // padding tile: only its (zero) statistics slot exists
-      if (a.partials && tid < 32 && n0 + (tid >> 1) < a.Cout) a.partials[((size_t)tile_id * a.Cout + n0 + (tid >> 1)) * 2 + (tid & 1)] = 0.0;
-      return;
-    }
-    od0 = td_i * G::TZ; oh0 = th_i * G::TY; ow0 = tw_i * G::TW;
+    int bt = tile_id;
+    const int tw_i = bt % a.ntw; bt /= a.ntw;
+    const int th_i = bt % a.nth; bt /= a.nth;
+    od0 = bt * G::TZ; oh0 = th_i * G::TY; ow0 = tw_i * G::TW;
   }
   const int wz = G::SLICES ? wid : 0, wh = G::SLICES ? 0 : wid * NR;
 
@@ -264,7 +255,7 @@ static int bf16_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth
   const bool slices = d->kd == 3 && nr >= 4;
   const int tz = slices ? 4 : 1, ty = slices ? nr : 4 * nr;
   *ntd = cdiv(d->D, tz); *nth = cdiv(d->H, ty); *ntw = cdiv(d->W, 16 * nh);
-  return cdiv(*ntd, 4) * cdiv(*nth, 4) * cdiv(*ntw, 4) * 64;    // launch size: whole 4x4x4 blocks of tiles (see the kernel)
+  return *ntd * *nth * *ntw;
 }
 
 static int g_bf16_debug = 0;
