@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--mode", default="auto", choices=["auto", "eager", "graph"])
     ap.add_argument("--patches", type=int, default=8, help="c3: patches per rank taken from the queue")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: BASELINE configs[4] mixed precision (bf16 MFMA operands in the 3x3x3 convs, fp32 accumulate / storage / Adam); "
+                         "a SECOND bench line, the headline stays fp32")
     ap.add_argument("--concurrent", type=int, default=6, help="c3: patches optimised side by side on one GPU")
     a = ap.parse_args()
     if a.steps is None:
@@ -61,9 +64,12 @@ def parse():
     return a
 
 
+PRECISION = "fp32"
+
+
 def default_args(upsample, epochs=3000):
     from deep_prior_interpolation_amd.parameter import parse_arguments
-    return parse_arguments(["--imgdir", "synthetic", "--datadim", "3d", "--net", "multiunet", "--inputdepth", "64",
+    return parse_arguments(["--precision", PRECISION, "--imgdir", "synthetic", "--datadim", "3d", "--net", "multiunet", "--inputdepth", "64",
                             "--upsample", upsample, "--loss", "mae", "--lr", "1e-3", "--gain", "40",
                             "--reg_noise_std", "0.03", "--noise_std", "0.1", "--epochs", str(epochs), "--gpu", "0"])
 
@@ -152,6 +158,7 @@ def run_c2(a, rank, world, device):
     T, args = make_interpolator(a.patch, a.upsample, device, seed=rank)
     V = int(np.prod(a.patch))
     T.optimizer = FusedAdam(T.net.parameters(), lr=args.lr)
+    ops.set_precision(a.precision)
 
     # dominant kernel for the roofline line: the heaviest single launch of the iteration, the full-resolution
     # ResPath 25->16 3x3x3 forward convolution (5.66 GF at 64^3, scales with V)
@@ -246,8 +253,9 @@ def run_c2(a, rank, world, device):
         cpu = cpu_baseline(a.patch, a.cpu_patch, a.upsample, a.cpu_iters, gpu_small_patch_rate(a.cpu_patch, a.upsample, device))
     return {"metric": "Adam iters/sec on 3D MultiRes-UNet per GPU", "value": round(world * a.steps / dt, 4), "unit": "it/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: MulResUnet3D defaults (5923614 params), patch %dx%dx%d, inputdepth 64, %s, MAE, "
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.precision == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": ("" if a.precision == "fp32" else "MIXED PRECISION (bf16 MFMA operands in the 3x3x3 convolutions, fp32 accumulate, fp32 "
+                                    "tensors / master weights / BatchNorm / Adam) — ") + "configs[1]: MulResUnet3D defaults (5923614 params), patch %dx%dx%d, inputdepth 64, %s, MAE, "
                                    "one independent patch per GPU, loop mode %s" % (tuple(a.patch) + (args.upsample, mode)),
                        "last_loss": T.history.loss[-1], "last_snr_db": T.history.snr[-1]},
             "roofline": roof, "cpu_baseline": cpu}
@@ -322,7 +330,9 @@ def run_c3(a, rank, world, device):
 
 
 def main():
+    global PRECISION
     a = parse()
+    PRECISION = a.precision
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
