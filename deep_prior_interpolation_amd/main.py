@@ -211,7 +211,8 @@ class Interpolator:
             mode = "eager" if (net_inputs is not None or a.save_every is not None or a.epochs < 3 or self.has_regularizer()
                                or a.data_forgetting_factor != 0 or int(np.prod(self.img.shape[:-1])) >= (1 << 20)) else "graph"
         self.optimizer = FusedAdam(self.net.parameters(), lr=a.lr)
-        ops.set_precision(getattr(a, "precision", "fp32"))
+        if getattr(a, "precision", "fp32") != "fp32" or "DPI_PRECISION" not in os.environ:     # (the environment variable is a tools-only override)
+            ops.set_precision(getattr(a, "precision", "fp32"))
         ops.set_weight_grad_overlap(mode == "eager" and int(np.prod(self.img.shape[:-1])) >= (1 << 20))
         start = time()
         if mode == "graph":
