@@ -38,6 +38,7 @@ SIGNATURES = {
     "dpi_device_info": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_Z), C.c_char_p, _I]),
     "dpi_profile_marker": (_I, [_I, _P]),
     "dpi_set_bw_tuning": (None, [_I, _I]),
+    "dpi_set_bf16_debug": (None, [_I]),
     "dpi_conv_fwd_stat_blocks": (_I, [_DESC]),
     "dpi_conv_fwd": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P]),
     "dpi_conv_bwd_data": (_I, [_DESC, _P, _P, _P, _I, _P]),

@@ -259,9 +259,22 @@ static int bf16_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth
 }
 
 static int g_bf16_debug = 0;
-extern "C" void dpi_set_bf16_debug(int flags) { g_bf16_debug = flags; }
+static int g_bf16_all = 0;      // 1: every 3x3(x3) stride-1 convolution (tests); 0: only where the kernel beats the fp32 one
+extern "C" void dpi_set_bf16_debug(int flags) { g_bf16_debug = flags & 7; g_bf16_all = (flags >> 3) & 1; }
 
-bool dpi_conv_bf16_usable(const dpi_conv_desc* d) { return d->precision == 1 && d->k == 3 && d->stride == 1; }
+// Where the mode applies (measured in the iteration, profiles/r02_bf16_kernel_stats_layers.txt): the big-tile variant — full
+// resolution and the first coarse level — is 1.2-2.1x faster than the fp32 kernels except for 4 input channels (one half-empty K
+// block per tile); the row-band variants of the coarse levels (hundreds of channels = tens of 8-channel groups, two barriers and
+// one exposed load latency each, few tiles) are slower than the fp32 kernels and keep fp32 arithmetic.
+static bool bf16_pays(const dpi_conv_desc* d, bool flip) {
+  if (g_bf16_all) return true;
+  const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
+  int nr, nh;
+  bf16_variant(d, cout, &nr, &nh);
+  return nr == 4 && cin > 4;
+}
+
+bool dpi_conv_bf16_usable(const dpi_conv_desc* d, bool flip) { return d->precision == 1 && d->k == 3 && d->stride == 1 && bf16_pays(d, flip); }
 
 int dpi_conv_bf16_stat_blocks(const dpi_conv_desc* d) {
   int nr, nh, a, b, c;

@@ -450,7 +450,7 @@ int dpi_conv_bwd_data_s2_mfma_run(const dpi_conv_desc* d, const float* dy, const
 void dpi_mfma_variant(const dpi_conv_desc* d, int cout, int* nr, int* nh);
 int dpi_mfma_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth, int* ntw);
 bool dpi_mfma_half_tile(const dpi_conv_desc* d, bool flip);
-bool dpi_conv_bf16_usable(const dpi_conv_desc* d);
+bool dpi_conv_bf16_usable(const dpi_conv_desc* d, bool flip);
 int dpi_conv_bf16_stat_blocks(const dpi_conv_desc* d);
 int dpi_conv_bf16_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
                       double* partials, bool flip, int accumulate, hipStream_t st);
@@ -468,7 +468,7 @@ extern "C" int dpi_conv_fwd_stat_blocks(const dpi_conv_desc* d) {
   if (check_desc(d) != DPI_OK) return 0;
   int Do, Ho, Wo;
   dpi_conv_out_dims(d, &Do, &Ho, &Wo);
-  if (dpi_conv_bf16_usable(d)) return dpi_conv_bf16_stat_blocks(d);
+  if (dpi_conv_bf16_usable(d, false)) return dpi_conv_bf16_stat_blocks(d);
   if (d->k == 1 && d->Cout >= g_mfma_min_cout) {
     int vpb, mt;
     dpi_conv_pw_mfma_plan((size_t)Do * Ho * Wo, d->Cout, &vpb, &mt);
@@ -495,7 +495,7 @@ static int conv_run(const dpi_conv_desc* d, const float* x, const float* chain, 
   const int taps = d->kd * d->k * d->k;
   const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
   const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
-  if (dpi_conv_bf16_usable(d)) return dpi_conv_bf16_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
+  if (dpi_conv_bf16_usable(d, flip)) return dpi_conv_bf16_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
   if (d->k == 3 && cout >= g_mfma_min_cout && (d->stride == 1 || !flip))
     return dpi_conv_mfma_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
   if (d->k == 1 && cout >= g_mfma_min_cout) return dpi_conv_pw_mfma_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);

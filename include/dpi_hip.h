@@ -53,6 +53,9 @@ int dpi_profile_marker(int id, void* stream);
 /* Tuning knobs of the backward-weight MFMA launch plan (experiments / tools only): workgroups aimed at (<= 0 keeps the
  * current value) and the XCD-aware workgroup order (0 / 1; < 0 keeps it). */
 void dpi_set_bw_tuning(int want_workgroups, int xcd_order);
+/* bf16 convolution kernel, tests / tools only: bits 0-2 skip phases (timing experiments, wrong results), bit 3 routes EVERY
+ * 3x3(x3) stride-1 convolution of a precision = 1 descriptor through it (default: only the shapes where it beats the fp32 kernels). */
+void dpi_set_bf16_debug(int flags);
 
 /* ---------------------------------------------------------------- convolution ------------------
  * Replaces nn.Conv3d / nn.Conv2d built at architectures/base.py:123,176 (k in {1,3}, stride in {1,2},

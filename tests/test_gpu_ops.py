@@ -403,6 +403,8 @@ def test_conv_bf16_mode_vs_oracle(ops, cin, cout, shape, k, monkeypatch):
     (2) With arbitrary fp32 inputs the result must equal the oracle applied to the bf16-rounded operands (2e-6) and sit within
         the bf16 rounding envelope of the exact result (5e-3 norm-wise).  Backward-data runs the same kernel (flipped weights)."""
     monkeypatch.setattr(ops, "PRECISION", 1)
+    from deep_prior_interpolation_amd import _lib
+    _lib.load().dpi_set_bf16_debug(8)          # every 3x3x3 stride-1 conv through the bf16 kernel (by default only where it pays)
     gen = torch.Generator().manual_seed(cin * 1000 + cout)
     x = torch.randn((1, cin) + shape, generator=gen)
     w = torch.randn((cout, cin, k, k, k), generator=gen) * (1.0 / np.sqrt(cin * k ** 3))
@@ -430,6 +432,7 @@ def test_conv_bf16_mode_vs_oracle(ops, cin, cout, shape, k, monkeypatch):
     ops.raw_conv_bwd_data(d, dy.to(DEV), wg, acc, accumulate=True)
     plain = torch.empty_like(acc)
     ops.raw_conv_bwd_data(d, dy.to(DEV), wg, plain)
+    _lib.load().dpi_set_bf16_debug(0)
     assert rel(acc, base + plain) < 1e-6
 
 
@@ -438,6 +441,7 @@ def test_conv_bf16_mode_chain_and_stats(ops, monkeypatch):
     from deep_prior_interpolation_amd import _lib
     monkeypatch.setattr(ops, "PRECISION", 1)
     L = _lib.load()
+    L.dpi_set_bf16_debug(8)
     gen = torch.Generator().manual_seed(5)
     cin, cout, shape = 13, 9, (7, 12, 37)
     x = torch.randn((1, cin) + shape, generator=gen)
@@ -463,3 +467,4 @@ def test_conv_bf16_mode_chain_and_stats(ops, monkeypatch):
     yn = y.double().cpu().numpy()[0]
     np.testing.assert_allclose(p[:, 0], yn.reshape(cout, -1).sum(1), rtol=1e-9, atol=1e-7)
     np.testing.assert_allclose(p[:, 1], (yn.reshape(cout, -1) ** 2).sum(1), rtol=1e-9)
+    L.dpi_set_bf16_debug(0)
