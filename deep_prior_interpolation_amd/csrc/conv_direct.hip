@@ -427,7 +427,9 @@ int check_desc(const dpi_conv_desc* d) {
   DPI_REQUIRE(d->kd == d->k || d->D == 1, "conv: 2-D kernels need D == 1");
   DPI_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride must be 1 or 2 (got %d)", d->stride);
   DPI_REQUIRE(d->k == 3 || d->stride == 1, "conv: 1x1 convolution supports stride 1 only");
-  DPI_REQUIRE((size_t)d->D * d->H * d->W < (1ull << 31), "conv: spatial volume exceeds int32 indexing");
+  // the stencil kernels address a channel through 32-bit BYTE offsets (buffer loads): 4 * D*H*W must stay below 2^31
+  DPI_REQUIRE((size_t)d->D * d->H * d->W < (1ull << 29), "conv: spatial volume %d x %d x %d exceeds the 32-bit byte offsets of the kernels (2^29 voxels per patch)",
+              d->D, d->H, d->W);
   DPI_REQUIRE(d->precision == 0 || d->precision == 1, "conv: precision must be 0 (fp32) or 1 (bf16 operands), got %d", d->precision);
   return DPI_OK;
 }

@@ -966,6 +966,9 @@ extern "C" int dpi_upsample2x_bwd(const float* dy, int C, int D, int H, int W, i
     hipStream_t st = (hipStream_t)stream;
     float* t1 = ws;                                     // [C][Do][Ho][W]
     float* t2 = ws + (size_t)C * Do * Ho * W;           // [C][Do][H][W]
+    // the axis kernel indexes one [n][inner] (output) / [no][inner] (input) slab and the slab count with 32 bits
+    DPI_REQUIRE((size_t)C * Do * Ho < (1ull << 32) && (size_t)Do * Ho * Wo < (1ull << 31) && (size_t)Do * H * W < (1ull << 31),
+                "upsample_bwd: %d x %d x %d x %d exceeds the 32-bit slab indexing of the separable adjoint", C, Do, Ho, Wo);
     auto launch = [&](const float* src, float* dst, size_t outer, int n, int no, size_t inner) {
       const unsigned gx = (unsigned)cdivz((size_t)n * inner, 256);
       // enough slabs per launch to fill the chip, each workgroup then strides over the rest
