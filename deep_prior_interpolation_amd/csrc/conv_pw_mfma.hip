@@ -299,20 +299,11 @@ PwBwPlan pw_bw_plan(const dpi_conv_desc* d) {
 // (a few thousand voxels, hundreds of channels) would leave most CUs idle that way, so they get 256-voxel workgroups
 // and, if that is still not ~4 waves per CU, one channel tile per workgroup.
 void dpi_conv_pw_mfma_plan(size_t V, int cout, int* vox_per_block, int* mt) {
-  // channel tiles per workgroup: every extra pass over the output channels re-reads the whole input, so take the fewest
-  // passes with up to 6 tiles (96 channels; backward-data of the 67 -> 25 shortcut has 67 "output" channels: 4 tiles = 2 passes
-  // with a second pass of 3 channels, 5 tiles = 1 pass), and among equal pass counts the fewest tiles (registers)
   int m = cout <= 16 ? 1 : (cout <= 32 ? 2 : 4);
-  if (cout > 64) {
-    int best = 4;
-    for (int t = 5; t <= 6; ++t)
-      if (cdiv(cout, 16 * t) < cdiv(cout, 16 * best)) best = t;
-    m = best;
-  }
   int vpb = 1024;
   auto waves = [&]() { return (long)cdivz(V, vpb) * (vpb / 256) * cdiv(cout, 16 * m); };
   if (waves() < 1024) vpb = 256;
-  if (waves() < 1024 && m >= 4) m = 2;
+  if (waves() < 1024 && m == 4) m = 2;
   if (waves() < 1024 && m == 2) m = 1;
   *vox_per_block = vpb;
   *mt = m;
@@ -331,9 +322,7 @@ int dpi_conv_pw_mfma_run(const dpi_conv_desc* d, const float* x, const float* ch
   const dim3 grid(gx, cdiv(cout, 16 * mt));
   if (mt == 1) { if (wlds) conv_pw_mfma_kernel<1, true><<<grid, 256, 0, st>>>(a); else conv_pw_mfma_kernel<1, false><<<grid, 256, 0, st>>>(a); }
   else if (mt == 2) { if (wlds) conv_pw_mfma_kernel<2, true><<<grid, 256, 0, st>>>(a); else conv_pw_mfma_kernel<2, false><<<grid, 256, 0, st>>>(a); }
-  else if (mt == 4) { if (wlds) conv_pw_mfma_kernel<4, true><<<grid, 256, 0, st>>>(a); else conv_pw_mfma_kernel<4, false><<<grid, 256, 0, st>>>(a); }
-  else if (mt == 5) { if (wlds) conv_pw_mfma_kernel<5, true><<<grid, 256, 0, st>>>(a); else conv_pw_mfma_kernel<5, false><<<grid, 256, 0, st>>>(a); }
-  else { if (wlds) conv_pw_mfma_kernel<6, true><<<grid, 256, 0, st>>>(a); else conv_pw_mfma_kernel<6, false><<<grid, 256, 0, st>>>(a); }
+  else { if (wlds) conv_pw_mfma_kernel<4, true><<<grid, 256, 0, st>>>(a); else conv_pw_mfma_kernel<4, false><<<grid, 256, 0, st>>>(a); }
   return dpi_check_launch("conv_pw_mfma");
 }
 
