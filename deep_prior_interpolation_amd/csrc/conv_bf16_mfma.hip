@@ -68,7 +68,7 @@ __device__ __forceinline__ int xcd_tile_b(int bid, int ntiles) {        // conti
 }
 
 template <int KD, int NR, int NH, bool FLIP>
-__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(BArgs a) {
+__global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
   using G = GeoB<KD, NR, NH>;
   constexpr int TAPS = G::TAPS, NTG = G::NTG, PD = (KD - 1) / 2, NT = NR * NH;
   __shared__ __attribute__((aligned(16))) unsigned xl[G::TILE * 4];        // [position][8 bf16]
@@ -182,16 +182,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(BArgs a) {
     if (c0 + 8 < a.Cin && !(a.debug & 2)) { load_x(c0 + 8); load_w(c0 + 8); }   // next group behind this group's MFMAs
     if (a.debug & 1) continue;
 
-    bf16x8 af[NTG];
-#pragma unroll
-    for (int g = 0; g < NTG; ++g) af[g] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wl + (g * 64 + lane) * 8));
 #pragma unroll
     for (int g = 0; g < NTG; ++g) {
+      // the A fragment of this tap group only lives across its NT MFMAs (7 resident fragments cost 28 registers = the
+      // third wave per SIMD)
+      const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wl + (g * 64 + lane) * 8));
 #pragma unroll
       for (int t = 0; t < NT; ++t) {                           // consecutive MFMAs go to different accumulators
         const int p = pbase + toff[g] + (t / NH) * G::IW + (t % NH) * 16;
         const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xl + p * 4));
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g], b, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b, acc[t], 0, 0, 0);
       }
     }
   }
