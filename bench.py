@@ -241,13 +241,25 @@ def run_c2(a, rank, world, device):
                 whole["measured_hbm_bytes_per_iteration"] = wi["hbm_bytes_per_iteration"]
                 whole["measured_over_algorithmic"] = round(wi["hbm_bytes_per_iteration"] / bmin, 3)
                 whole["measured_hbm_gbs"] = round(wi["hbm_bytes_per_iteration"] / (ms * 1e-3) / 1e9, 1)
-        roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<3,4,2,tail-packed> fwd 25->16 k3 @%dx%dx%d" % tuple(a.patch),
-                "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),
-                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                "algorithmic_bytes": 4.0 * (25 + 16) * V, "launch_ms": round(dom_ms, 4), "launches_timed": len(durs), "launch_timing": timing_src,
-                "note": "fp32 FMA-bound stencil (AI 41-44 FLOP/B > ridge 19.7); peak = nominal fp32 vector = fp32 MFMA rate",
-                "frac_of_sustained_mfma": round(ach / FP32_SUSTAINED_TFLOPS, 4), "sustained_mfma_tflops": FP32_SUSTAINED_TFLOPS,
-                "whole_iteration": whole}
+        if a.precision == "fp32":
+            roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<3,4,2,tail-packed> fwd 25->16 k3 @%dx%dx%d" % tuple(a.patch),
+                    "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),
+                    "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                    "algorithmic_bytes": 4.0 * (25 + 16) * V, "launch_ms": round(dom_ms, 4), "launches_timed": len(durs), "launch_timing": timing_src,
+                    "note": "fp32 FMA-bound stencil (AI 41-44 FLOP/B > ridge 19.7); peak = nominal fp32 vector = fp32 MFMA rate",
+                    "frac_of_sustained_mfma": round(ach / FP32_SUSTAINED_TFLOPS, 4), "sustained_mfma_tflops": FP32_SUSTAINED_TFLOPS,
+                    "whole_iteration": whole}
+        else:
+            # bf16 MFMA runs at 16x the fp32 matrix rate (2.5 PFLOP/s dense): the same launch is bound by HBM (AI 132 FLOP/B < ridge 312)
+            alg_bytes = 4.0 * (25 + 16) * V
+            gbs = alg_bytes / (dom_ms * 1e-3) / 1e9
+            whole.pop("measured_hbm_bytes_per_iteration", None); whole.pop("measured_over_algorithmic", None); whole.pop("measured_hbm_gbs", None)
+            roof = {"bound": "hbm", "kernel": "conv_bf16_kernel<3,4,2,false> fwd 25->16 k3 @%dx%dx%d (bf16 operands, fp32 accumulate)" % tuple(a.patch),
+                    "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes": alg_bytes, "launch_ms": round(dom_ms, 4), "launches_timed": len(durs), "launch_timing": timing_src,
+                    "achieved_tflops": round(ach, 1),
+                    "note": "fp32 tensors in HBM (the mode rounds operands on the way into LDS); traffic not measured for this mode",
+                    "whole_iteration": whole}
     cpu = None
     if not (a.no_cpu_baseline or world > 1):
         cpu = cpu_baseline(a.patch, a.cpu_patch, a.upsample, a.cpu_iters, gpu_small_patch_rate(a.cpu_patch, a.upsample, device))
