@@ -87,6 +87,37 @@ def test_conv_forward_crops_vs_oracle_at_bench_size(ops, cin, cout, k, stride):
     assert rel(y12, y + y2) < 5e-6
 
 
+@pytest.mark.parametrize("cin,cout", [(25, 16), (67, 4), (8, 13)])
+def test_conv_bf16_mode_crops_at_bench_size(ops, cin, cout, monkeypatch):
+    """--precision bf16 at the bench size (conv_bf16_kernel<3,4,2>): with bf16-representable operands the kernel must match the
+    fp64 oracle on crops as tightly as the fp32 path; forward and backward-data (flipped weights, channel roles swapped)."""
+    monkeypatch.setattr(ops, "PRECISION", 1)
+    gen = torch.Generator(device=DEV).manual_seed(cin * 100 + cout + 3)
+    x = torch.randn((1, cin) + FULL, device=DEV, generator=gen).bfloat16().float()
+    w = (torch.randn((cout, cin, 3, 3, 3), device=DEV, generator=gen) / np.sqrt(cin * 27)).bfloat16().float()
+    b = torch.randn(cout, device=DEV, generator=gen)
+    y = ops.conv(x, w, b, 1)
+    rng = np.random.RandomState(cin + cout)
+    worst = 0.0
+    for box in _boxes(FULL, rng):
+        ref = _oracle_conv_on_crop(x, w, b, box, 3, 1, FULL)
+        got = y[:, :, box[0][0]:box[0][1], box[1][0]:box[1][1], box[2][0]:box[2][1]]
+        worst = max(worst, rel(got, ref))
+    assert worst < 5e-6, worst
+    # backward-data = forward conv of dy with the flipped, transposed weights
+    dy = torch.randn((1, cout) + FULL, device=DEV, generator=gen).bfloat16().float()
+    d = ops.make_desc(x, w, 1)
+    dx = torch.empty_like(x)
+    ops.raw_conv_bwd_data(d, dy, w, dx)
+    wt = w.flip(2, 3, 4).transpose(0, 1).contiguous()
+    worst = 0.0
+    for box in _boxes(FULL, rng, n_random=2):
+        ref = _oracle_conv_on_crop(dy, wt, None, box, 3, 1, FULL)
+        got = dx[:, :, box[0][0]:box[0][1], box[1][0]:box[1][1], box[2][0]:box[2][1]]
+        worst = max(worst, rel(got, ref))
+    assert worst < 5e-6, worst
+
+
 @pytest.mark.parametrize("cin,cout,k,stride", LAYERS)
 def test_conv_backward_at_bench_size(ops, cin, cout, k, stride):
     gen = torch.Generator(device=DEV).manual_seed(cin * 100 + cout + 7)

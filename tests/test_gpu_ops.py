@@ -392,7 +392,9 @@ def test_channel_dropout_semantics(ops):
 # ---- BASELINE configs[4] mixed precision: bf16 operands, fp32 accumulate (csrc/conv_bf16_mfma.hip) ------------------------------
 BF16_CASES = [(25, 16, (12, 9, 40), 3), (64, 4, (8, 12, 36), 3), (4, 8, (9, 17, 33), 3), (8, 13, (8, 8, 32), 3), (25, 1, (8, 16, 32), 3),
               (67, 4, (6, 10, 34), 3), (35, 71, (8, 8, 8), 3), (71, 142, (4, 4, 4), 3), (17, 26, (6, 6, 6), 3), (105, 64, (4, 8, 16), 3),
-              (9, 20, (16, 20, 70), 3), (16, 16, (3, 5, 17), 3), (5, 3, (1, 1, 1), 3), (51, 32, (32, 32, 64), 3)]
+              (9, 20, (16, 20, 70), 3), (16, 16, (3, 5, 17), 3), (5, 3, (1, 1, 1), 3), (51, 32, (32, 32, 64), 3),
+              # >= 512 tiles: the 4x4x32-tile variant the mode uses at full resolution (ragged edges in every axis)
+              (25, 16, (64, 64, 64), 3), (8, 13, (62, 66, 70), 3), (4, 40, (64, 60, 64), 3)]
 
 
 @pytest.mark.parametrize("cin,cout,shape,k", BF16_CASES)
