@@ -283,6 +283,47 @@ def test_noise_statistics():
     assert torch.equal(out2, out3)                   # deterministic given (seed, step)
 
 
+def test_fill_normal_and_noise_distribution_and_stream_independence():
+    """z = noise_std * N(0,1) (dpi_fill_normal, reference main.py:62-64 / utils/torch.py:61-73) and the per-iteration perturbation
+    (dpi_noise_add): Kolmogorov-Smirnov against the normal CDF, tails out to 4.5 sigma, and independence between the streams the
+    drivers actually use — different seeds (one per patch), z vs perturbation (stream id), consecutive patches of one Interpolator."""
+    from scipy import stats
+    from deep_prior_interpolation_amd import _lib
+    L = _lib.load()
+    n = 1 << 22
+
+    def fill(seed, stream_id, mean=0.0, std=0.1):
+        out = torch.empty(n, device=DEV)
+        _lib.check(L.dpi_fill_normal(_lib.ptr(out), n, mean, std, seed, stream_id, _lib.stream()))
+        return out.double().cpu().numpy()
+
+    def noise(seed, step):
+        z = torch.zeros(n, device=DEV)
+        out = torch.empty(n, device=DEV)
+        st = torch.tensor([step], dtype=torch.int64, device=DEV)
+        _lib.check(L.dpi_noise_add(_lib.ptr(z), n, 1.0, seed, _lib.ptr(st), _lib.ptr(out), _lib.stream()))
+        return out.double().cpu().numpy()
+    zid = (0xFFFFFFFF << 32)
+    a = fill(0, zid)
+    assert abs(a.mean()) < 3e-4 and abs(a.std() - 0.1) < 2e-4
+    sub = a[::16] / 0.1                                                  # 262144 samples: KS critical value at 1 % is 0.0032
+    assert stats.kstest(sub, "norm").statistic < 0.0032
+    for k in (2.0, 3.0, 4.0, 4.5):                                       # two-sided tail mass within 4 binomial sigma
+        p = 2 * stats.norm.sf(k)
+        got = np.mean(np.abs(a / 0.1) > k)
+        assert abs(got - p) < 4 * np.sqrt(p / n) + 1e-9, (k, got, p)
+    b = fill(0, zid, mean=2.0, std=0.5)
+    np.testing.assert_allclose((b - 2.0) / 0.5, a / 0.1, rtol=0, atol=2e-6)   # same draw, affine map
+    pairs = {"another seed": fill(1, zid), "next patch of the same Interpolator": fill(0, zid | 1),
+             "perturbation stream, same seed": noise(0, 1) * 0.1, "perturbation, next step": noise(0, 2) * 0.1,
+             "perturbation, another seed": noise(1, 1) * 0.1}
+    for name, v in pairs.items():
+        assert abs(np.corrcoef(a, v)[0, 1]) < 3e-3, name                   # 4 M samples: |r| ~ 5e-4
+        assert abs(np.corrcoef(a[:-1], v[1:])[0, 1]) < 3e-3, name          # ... and at lag 1
+        assert stats.kstest(v[::16] / 0.1, "norm").statistic < 0.0032, name
+    assert abs(np.corrcoef(noise(0, 1), noise(1, 1))[0, 1]) < 3e-3
+
+
 def test_overlap_add_vs_oracle():
     from deep_prior_interpolation_amd import _lib
     from deep_prior_interpolation_amd.utils import window_origins
