@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--mode", default="auto", choices=["auto", "eager", "graph"])
     ap.add_argument("--patches", type=int, default=8, help="c3: patches per rank taken from the queue")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "split"],
                     help="bf16: BASELINE configs[4] mixed precision (bf16 MFMA operands in the 3x3x3 convs, fp32 accumulate / storage / Adam); "
                          "a SECOND bench line, the headline stays fp32")
     ap.add_argument("--concurrent", type=int, default=6, help="c3: patches optimised side by side on one GPU")
@@ -254,7 +254,8 @@ def run_c2(a, rank, world, device):
             alg_bytes = 4.0 * (25 + 16) * V
             gbs = alg_bytes / (dom_ms * 1e-3) / 1e9
             whole.pop("measured_hbm_bytes_per_iteration", None); whole.pop("measured_over_algorithmic", None); whole.pop("measured_hbm_gbs", None)
-            roof = {"bound": "hbm", "kernel": "conv_bf16_kernel<3,4,2,false> fwd 25->16 k3 @%dx%dx%d (bf16 operands, fp32 accumulate)" % tuple(a.patch),
+            roof = {"bound": "hbm", "kernel": "conv_bf16_kernel fwd 25->16 k3 @%dx%dx%d (%s, fp32 accumulate)"
+                              % (tuple(a.patch) + ("bf16 operands" if a.precision == "bf16" else "three-term bf16 split, 6 products",)),
                     "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes": alg_bytes, "launch_ms": round(dom_ms, 4), "launches_timed": len(durs), "launch_timing": timing_src,
                     "achieved_tflops": round(ach, 1),
@@ -265,9 +266,11 @@ def run_c2(a, rank, world, device):
         cpu = cpu_baseline(a.patch, a.cpu_patch, a.upsample, a.cpu_iters, gpu_small_patch_rate(a.cpu_patch, a.upsample, device))
     return {"metric": "Adam iters/sec on 3D MultiRes-UNet per GPU", "value": round(world * a.steps / dt, 4), "unit": "it/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.precision == "fp32" else "bf16", "data": "synthetic",
-            "config": {"workload": ("" if a.precision == "fp32" else "MIXED PRECISION (bf16 MFMA operands in the 3x3x3 convolutions, fp32 accumulate, fp32 "
-                                    "tensors / master weights / BatchNorm / Adam) — ") + "configs[1]: MulResUnet3D defaults (5923614 params), patch %dx%dx%d, inputdepth 64, %s, MAE, "
+            "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "split": "f32 (3 x bf16 split)"}[a.precision], "data": "synthetic",
+            "config": {"workload": {"fp32": "", "bf16": "MIXED PRECISION (bf16 MFMA operands in the 3x3x3 convolutions, fp32 accumulate, fp32 tensors / master "
+                                                          "weights / BatchNorm / Adam) — ",
+                                   "split": "SPLIT MODE (forward / backward-data operands split exactly into three bf16 terms, six partial products "
+                                            "accumulated in fp32: fp32-class accuracy on the bf16 matrix cores) — "}[a.precision] + "configs[1]: MulResUnet3D defaults (5923614 params), patch %dx%dx%d, inputdepth 64, %s, MAE, "
                                    "one independent patch per GPU, loop mode %s" % (tuple(a.patch) + (args.upsample, mode)),
                        "last_loss": T.history.loss[-1], "last_snr_db": T.history.snr[-1]},
             "roofline": roof, "cpu_baseline": cpu}

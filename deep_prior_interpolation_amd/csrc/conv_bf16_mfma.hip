@@ -11,6 +11,12 @@
 //         ds_read_b128 at position(vox) + offset(tap) — 16 consecutive positions per 16-lane group, conflict-free.
 //     A = weights of the 8-channel group, converted to bf16 by the workgroup once per group and shared through LDS as ready-made
 //         fragments [g][lane][8] (the torch layout [Cout][Cin][27] would cost every lane 8 strided loads per fragment).
+// NS = 3 (precision = 2, "split" mode): every fp32 operand is split EXACTLY into three bf16 terms x = h + m + l (8 + 8 + 8
+// significant bits; h = rne(x), m = rne(x - h), l = rne(x - h - m), each difference exact in fp32) and six of the nine partial
+// products — hh, hm, mh, mm, hl, lh, i.e. all those >= 2^-16 of the full product — are accumulated in fp32.  The three dropped
+// ones are <= 2^-24 relative each, the size of one fp32 rounding, so the result carries fp32-class accuracy (verified against
+// the fp64 oracle at the fp32 path's own tolerance) at 16 / 6 = 2.7 x the fp32 matrix rate; since the kernel is bound by its
+// staging loads, not by the matrix pipe, the extra MFMAs are close to free.
 // Workgroup = 4 waves = output tile 4x4x32 (or the small 1x8x16/32 variants for coarse levels), as in conv_mfma.hip; D layout,
 // epilogue (bias, BatchNorm {sum, sum^2} partials, gradient fan-in) are those of the fp32 kernel.
 #include "common.h"
@@ -67,12 +73,22 @@ __device__ __forceinline__ int xcd_tile_b(int bid, int ntiles) {        // conti
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
 
-template <int KD, int NR, int NH, bool FLIP>
+// exact three-term split of an fp32 value into bf16 bit patterns
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+  h = bf16_bits(x);
+  const float r1 = x - __builtin_bit_cast(float, h << 16);
+  m = bf16_bits(r1);
+  const float r2 = r1 - __builtin_bit_cast(float, m << 16);
+  l = bf16_bits(r2);
+}
+
+template <int KD, int NR, int NH, bool FLIP, int NS = 1>
 __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
   using G = GeoB<KD, NR, NH>;
   constexpr int TAPS = G::TAPS, NTG = G::NTG, PD = (KD - 1) / 2, NT = NR * NH;
-  __shared__ __attribute__((aligned(16))) unsigned xl[G::TILE * 4];        // [position][8 bf16]
-  __shared__ __attribute__((aligned(16))) unsigned short wl[NTG * 64 * 8];  // [g][lane][8 bf16]: A fragments
+  constexpr int XW = G::TILE * 4, WW = NTG * 64 * 8;                        // words / halfwords per operand copy
+  __shared__ __attribute__((aligned(16))) unsigned xl[NS * XW];             // [term][position][8 bf16]
+  __shared__ __attribute__((aligned(16))) unsigned short wl[NS * WW];       // [term][g][lane][8 bf16]: A fragments
   __shared__ double red[4][16][2];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -168,14 +184,31 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
 #pragma unroll
       for (int e = 0; e < G::E; ++e) {
         const int idx = tid + e * 256;
-        if ((e + 1) * 256 <= G::TILE || idx < G::TILE)
-          *reinterpret_cast<u32x4*>(xl + idx * 4) = (u32x4){pack_bf16(sr[0][e], sr[1][e]), pack_bf16(sr[2][e], sr[3][e]),
-                                                            pack_bf16(sr[4][e], sr[5][e]), pack_bf16(sr[6][e], sr[7][e])};
+        if ((e + 1) * 256 <= G::TILE || idx < G::TILE) {
+          if constexpr (NS == 1) {
+            *reinterpret_cast<u32x4*>(xl + idx * 4) = (u32x4){pack_bf16(sr[0][e], sr[1][e]), pack_bf16(sr[2][e], sr[3][e]),
+                                                              pack_bf16(sr[4][e], sr[5][e]), pack_bf16(sr[6][e], sr[7][e])};
+          } else {
+            unsigned h[8], m[8], l[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) split3(sr[c][e], h[c], m[c], l[c]);
+            *reinterpret_cast<u32x4*>(xl + idx * 4) = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+            *reinterpret_cast<u32x4*>(xl + XW + idx * 4) = (u32x4){m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16)};
+            *reinterpret_cast<u32x4*>(xl + 2 * XW + idx * 4) = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+          }
+        }
       }
 #pragma unroll
       for (int j = 0; j < G::WE; ++j) {
         const int q = tid + j * 256;
-        if ((j + 1) * 256 <= NTG * 512 || q < NTG * 512) wl[q] = (unsigned short)bf16_bits(wq[j]);
+        if ((j + 1) * 256 <= NTG * 512 || q < NTG * 512) {
+          if constexpr (NS == 1) wl[q] = (unsigned short)bf16_bits(wq[j]);
+          else {
+            unsigned h, m, l;
+            split3(wq[j], h, m, l);
+            wl[q] = (unsigned short)h; wl[WW + q] = (unsigned short)m; wl[2 * WW + q] = (unsigned short)l;
+          }
+        }
       }
     }
     __syncthreads();
@@ -186,12 +219,29 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
     for (int g = 0; g < NTG; ++g) {
       // the A fragment of this tap group only lives across its NT MFMAs (7 resident fragments cost 28 registers = the
       // third wave per SIMD)
-      const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wl + (g * 64 + lane) * 8));
+      auto frag_w = [&](int term) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wl + term * WW + (g * 64 + lane) * 8)); };
+      auto frag_x = [&](int term, int p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xl + term * XW + p * 4)); };
+      if constexpr (NS == 1) {
+        const bf16x8 af = frag_w(0);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {                           // consecutive MFMAs go to different accumulators
-        const int p = pbase + toff[g] + (t / NH) * G::IW + (t % NH) * 16;
-        const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xl + p * 4));
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b, acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) {                         // consecutive MFMAs go to different accumulators
+          const int p = pbase + toff[g] + (t / NH) * G::IW + (t % NH) * 16;
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_x(0, p), acc[t], 0, 0, 0);
+        }
+      } else {
+        const bf16x8 wh = frag_w(0), wm = frag_w(1), wlo = frag_w(2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int p = pbase + toff[g] + (t / NH) * G::IW + (t % NH) * 16;
+          const bf16x8 xh = frag_x(0, p), xm = frag_x(1, p), xlo = frag_x(2, p);
+          // smallest terms first: l*h, h*l (2^-16), m*m (2^-16), h*m, m*h (2^-8), h*h
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xlo, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[t], 0, 0, 0);
+        }
       }
     }
   }
@@ -245,10 +295,12 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
 
 // tile variant: the 4x4x32 tile (2-D: 1x16x32) while it still gives >= 512 workgroups, else row-band tiles of one depth slice.
 // (The 4x8x32 tile of the fp32 kernel needs 64 prefetch + 64 accumulator registers here and spills.)
+static int g_split_nh = 1;      // column blocks of the split-mode tile (tuning: dpi_set_bf16_debug bit 4 selects 2)
+static int g_bf16_nh = 2;       // ... of the bf16-mode tile (bit 5 selects 1)
 static void bf16_variant(const dpi_conv_desc* d, int cout, int* nr, int* nh) {
   const int tz = d->kd == 3 ? 4 : 1, ty = d->kd == 3 ? 4 : 16;
   const long nb = (long)cdiv(d->D, tz) * cdiv(d->H, ty) * cdiv(d->W, 32) * cdiv(cout, 16);
-  if (nb >= 512) { *nr = 4; *nh = 2; }
+  if (nb >= 512) { *nr = 4; *nh = d->precision == 2 ? g_split_nh : g_bf16_nh; }    // split mode: three operand copies in LDS -> 4x4x16 tile
   else { *nr = 2; *nh = d->W > 16 ? 2 : 1; }
 }
 static int bf16_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth, int* ntw) {
@@ -260,7 +312,7 @@ static int bf16_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth
 
 static int g_bf16_debug = 0;
 static int g_bf16_all = 0;      // 1: every 3x3(x3) stride-1 convolution (tests); 0: only where the kernel beats the fp32 one
-extern "C" void dpi_set_bf16_debug(int flags) { g_bf16_debug = flags & 7; g_bf16_all = (flags >> 3) & 1; }
+extern "C" void dpi_set_bf16_debug(int flags) { g_bf16_debug = flags & 7; g_bf16_all = (flags >> 3) & 1; g_split_nh = (flags & 16) ? 2 : 1; g_bf16_nh = (flags & 32) ? 1 : 2; }
 
 // Where the mode applies (measured in the iteration, profiles/r02_bf16_kernel_stats_layers.txt): the big-tile variant — full
 // resolution and the first coarse level — is 1.2-2.1x faster than the fp32 kernels except for 4 input channels (one half-empty K
@@ -274,7 +326,7 @@ static bool bf16_pays(const dpi_conv_desc* d, bool flip) {
   return nr == 4 && (cin > 4 || cout > 16);      // 4 -> 8 forward: 217 vs 196 us (fp32); 4 -> 67 (backward-data of 67 -> 4): 888 vs 1056 us
 }
 
-bool dpi_conv_bf16_usable(const dpi_conv_desc* d, bool flip) { return d->precision == 1 && d->k == 3 && d->stride == 1 && bf16_pays(d, flip); }
+bool dpi_conv_bf16_usable(const dpi_conv_desc* d, bool flip) { return d->precision >= 1 && d->k == 3 && d->stride == 1 && bf16_pays(d, flip); }
 
 int dpi_conv_bf16_stat_blocks(const dpi_conv_desc* d) {
   int nr, nh, a, b, c;
@@ -282,11 +334,12 @@ int dpi_conv_bf16_stat_blocks(const dpi_conv_desc* d) {
   return bf16_tiles(d, nr, nh, &a, &b, &c);
 }
 
-template <int KD, bool FLIP>
+template <int KD, bool FLIP, int NS>
 static void launch_bf16(const BArgs& a, int nr, int nh, dim3 grid, hipStream_t st) {
-  if (nr == 4) conv_bf16_kernel<KD, 4, 2, FLIP><<<grid, 256, 0, st>>>(a);
-  else if (nh == 2) conv_bf16_kernel<KD, 2, 2, FLIP><<<grid, 256, 0, st>>>(a);
-  else conv_bf16_kernel<KD, 2, 1, FLIP><<<grid, 256, 0, st>>>(a);
+  if (nr == 4 && nh == 2) conv_bf16_kernel<KD, 4, 2, FLIP, NS><<<grid, 256, 0, st>>>(a);
+  else if (nr == 4) conv_bf16_kernel<KD, 4, 1, FLIP, NS><<<grid, 256, 0, st>>>(a);
+  else if (nh == 2) conv_bf16_kernel<KD, 2, 2, FLIP, NS><<<grid, 256, 0, st>>>(a);
+  else conv_bf16_kernel<KD, 2, 1, FLIP, NS><<<grid, 256, 0, st>>>(a);
 }
 
 int dpi_conv_bf16_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
@@ -299,7 +352,12 @@ int dpi_conv_bf16_run(const dpi_conv_desc* d, const float* x, const float* chain
   BArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, accumulate, g_bf16_debug};
   const int ntiles = bf16_tiles(d, nr, nh, &a.ntd, &a.nth, &a.ntw);
   dim3 grid(ntiles, cdiv(cout, 16));
-  if (d->kd == 3) { if (flip) launch_bf16<3, true>(a, nr, nh, grid, st); else launch_bf16<3, false>(a, nr, nh, grid, st); }
-  else { if (flip) launch_bf16<1, true>(a, nr, nh, grid, st); else launch_bf16<1, false>(a, nr, nh, grid, st); }
+  if (d->precision == 2) {
+    if (d->kd == 3) { if (flip) launch_bf16<3, true, 3>(a, nr, nh, grid, st); else launch_bf16<3, false, 3>(a, nr, nh, grid, st); }
+    else { if (flip) launch_bf16<1, true, 3>(a, nr, nh, grid, st); else launch_bf16<1, false, 3>(a, nr, nh, grid, st); }
+  } else {
+    if (d->kd == 3) { if (flip) launch_bf16<3, true, 1>(a, nr, nh, grid, st); else launch_bf16<3, false, 1>(a, nr, nh, grid, st); }
+    else { if (flip) launch_bf16<1, true, 1>(a, nr, nh, grid, st); else launch_bf16<1, false, 1>(a, nr, nh, grid, st); }
+  }
   return dpi_check_launch("conv_bf16_mfma");
 }

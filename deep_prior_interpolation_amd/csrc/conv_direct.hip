@@ -430,7 +430,7 @@ int check_desc(const dpi_conv_desc* d) {
   // the stencil kernels address a channel through 32-bit BYTE offsets (buffer loads): 4 * D*H*W must stay below 2^31
   DPI_REQUIRE((size_t)d->D * d->H * d->W < (1ull << 29), "conv: spatial volume %d x %d x %d exceeds the 32-bit byte offsets of the kernels (2^29 voxels per patch)",
               d->D, d->H, d->W);
-  DPI_REQUIRE(d->precision == 0 || d->precision == 1, "conv: precision must be 0 (fp32) or 1 (bf16 operands), got %d", d->precision);
+  DPI_REQUIRE(d->precision >= 0 && d->precision <= 2, "conv: precision must be 0 (fp32), 1 (bf16 operands) or 2 (three-term bf16 split), got %d", d->precision);
   return DPI_OK;
 }
 

@@ -45,14 +45,17 @@ def conv_out(n, k, s):
 
 # 0: fp32 arithmetic (the reference's).  1: BASELINE configs[4] mixed precision — 3x3(x3) stride-1 convolutions feed bf16-rounded
 # operands to the matrix cores with fp32 accumulation; tensors, master weights, BatchNorm statistics and Adam stay fp32.
-PRECISION = 1 if os.environ.get("DPI_PRECISION", "fp32") == "bf16" else 0
+# 2: "split" mode — fp32 operands split exactly into three bf16 terms, six partial products accumulated in fp32: fp32-class accuracy
+# on the bf16 matrix cores (forward / backward-data of the shapes where the kernel wins).
+_PRECISIONS = {"fp32": 0, "bf16": 1, "split": 2}
+PRECISION = _PRECISIONS.get(os.environ.get("DPI_PRECISION", "fp32"), 0)
 
 
 def set_precision(name):
     global PRECISION
-    if name not in ("fp32", "bf16"):
-        raise ValueError("precision must be 'fp32' or 'bf16'")
-    PRECISION = 1 if name == "bf16" else 0
+    if name not in _PRECISIONS:
+        raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))
+    PRECISION = _PRECISIONS[name]
 
 
 def make_desc(x, w, stride):

@@ -70,7 +70,9 @@ typedef struct {
   int stride;       /* 1 or 2 (applies to D only when kd > 1) */
   /* 0 (default): fp32 operands, the reference's arithmetic.  1: mixed precision of BASELINE configs[4] — the operands of 3x3(x3)
    * stride-1 convolutions (forward, backward-data, backward-weight) are rounded to bf16 on their way into the matrix cores
-   * (v_mfma_f32_16x16x32_bf16, fp32 accumulate); tensors in HBM, master weights, BatchNorm statistics and Adam stay fp32. */
+   * (v_mfma_f32_16x16x32_bf16, fp32 accumulate); tensors in HBM, master weights, BatchNorm statistics and Adam stay fp32.
+   * 2: "split" mode — forward / backward-data operands are split exactly into three bf16 terms and six partial products are
+   * accumulated in fp32: fp32-class accuracy (same tolerance as precision 0 against the fp64 oracle) on the bf16 matrix cores. */
   int precision;
 } dpi_conv_desc;
 

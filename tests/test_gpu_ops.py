@@ -511,3 +511,38 @@ def test_conv_bf16_mode_chain_and_stats(ops, monkeypatch):
     np.testing.assert_allclose(p[:, 0], yn.reshape(cout, -1).sum(1), rtol=1e-9, atol=1e-7)
     np.testing.assert_allclose(p[:, 1], (yn.reshape(cout, -1) ** 2).sum(1), rtol=1e-9)
     L.dpi_set_bf16_debug(0)
+
+
+SPLIT_CASES = [(25, 16, (12, 9, 40), 3), (64, 4, (8, 12, 36), 3), (8, 13, (8, 8, 32), 3), (67, 4, (6, 10, 34), 3), (35, 71, (8, 8, 8), 3),
+               (17, 26, (6, 6, 6), 3), (9, 20, (16, 20, 70), 3), (25, 16, (64, 64, 64), 3), (8, 13, (62, 66, 70), 3), (4, 40, (64, 60, 64), 3)]
+
+
+@pytest.mark.parametrize("cin,cout,shape,k", SPLIT_CASES)
+def test_conv_split_mode_has_fp32_accuracy(ops, cin, cout, shape, k, monkeypatch):
+    """precision = 2: operands split exactly into three bf16 terms, six partial products accumulated in fp32.  ARBITRARY fp32
+    inputs, the fp32 path's own tolerance against the fp64 oracle (2e-6 norm-wise), forward and backward-data; and the error
+    must be of the same class as the fp32 kernel's on the same inputs (within 4x)."""
+    from deep_prior_interpolation_amd import _lib
+    gen = torch.Generator().manual_seed(cin * 1000 + cout + 1)
+    x = torch.randn((1, cin) + shape, generator=gen) * torch.logspace(-2, 2, cin).view(1, -1, 1, 1, 1)     # 4 decades of channel scale
+    w = torch.randn((cout, cin, k, k, k), generator=gen) * (1.0 / np.sqrt(cin * k ** 3))
+    b = torch.randn(cout, generator=gen)
+    dy = torch.randn((1, cout) + shape, generator=gen)
+    xr, wr = x.double().requires_grad_(True), w.double()
+    yr = O.conv_nd(xr, wr, b.double(), 1)
+    yr.backward(dy.double())
+    errs = {}
+    for prec in (2, 0):
+        monkeypatch.setattr(ops, "PRECISION", prec)
+        _lib.load().dpi_set_bf16_debug(8 if prec else 0)
+        try:
+            xg, wg = x.to(DEV), w.to(DEV)
+            y = ops.conv(xg, wg, b.to(DEV), 1)
+            d = ops.make_desc(xg, wg, 1)
+            dx = torch.empty_like(xg)
+            ops.raw_conv_bwd_data(d, dy.to(DEV), wg, dx)
+        finally:
+            _lib.load().dpi_set_bf16_debug(0)
+        errs[prec] = (rel(y, yr), rel(dx, xr.grad))
+    assert errs[2][0] < 2e-6 and errs[2][1] < 2e-6, errs
+    assert errs[2][0] < 4 * errs[0][0] + 1e-7 and errs[2][1] < 4 * errs[0][1] + 1e-7, errs

@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--mfma-min-cout", type=int, default=None)
     ap.add_argument("--bw-mfma-min-cout", type=int, default=None)
     ap.add_argument("--which", nargs="*", default=["fwd", "bwd_data", "bwd_weight"])
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "split"])
     ap.add_argument("--bf16-debug", type=int, default=0)
     ap.add_argument("--bw-want", type=int, default=0, help="backward-weight plan: workgroups aimed at (dpi_set_bw_tuning)")
     ap.add_argument("--bw-xcd", type=int, default=-1, help="backward-weight plan: XCD-aware workgroup order 0/1")
