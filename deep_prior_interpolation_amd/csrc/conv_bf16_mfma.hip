@@ -295,7 +295,8 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
 
 // tile variant: the 4x4x32 tile (2-D: 1x16x32) while it still gives >= 512 workgroups, else row-band tiles of one depth slice.
 // (The 4x8x32 tile of the fp32 kernel needs 64 prefetch + 64 accumulator registers here and spills.)
-static int g_split_nh = 1;      // column blocks of the split-mode tile (tuning: dpi_set_bf16_debug bit 4 selects 2)
+static int g_split_nh = 2;      // column blocks of the split-mode tile (tuning: dpi_set_bf16_debug bit 4 selects 1); measured: 4x4x32 at one
+                                // workgroup per CU (81 KB LDS) beats 4x4x16 at three on every layer but 25 -> 1
 static int g_bf16_nh = 2;       // ... of the bf16-mode tile (bit 5 selects 1)
 static void bf16_variant(const dpi_conv_desc* d, int cout, int* nr, int* nh) {
   const int tz = d->kd == 3 ? 4 : 1, ty = d->kd == 3 ? 4 : 16;
@@ -312,7 +313,7 @@ static int bf16_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth
 
 static int g_bf16_debug = 0;
 static int g_bf16_all = 0;      // 1: every 3x3(x3) stride-1 convolution (tests); 0: only where the kernel beats the fp32 one
-extern "C" void dpi_set_bf16_debug(int flags) { g_bf16_debug = flags & 7; g_bf16_all = (flags >> 3) & 1; g_split_nh = (flags & 16) ? 2 : 1; g_bf16_nh = (flags & 32) ? 1 : 2; }
+extern "C" void dpi_set_bf16_debug(int flags) { g_bf16_debug = flags & 7; g_bf16_all = (flags >> 3) & 1; g_split_nh = (flags & 16) ? 1 : 2; g_bf16_nh = (flags & 32) ? 1 : 2; }
 
 // Where the mode applies (measured in the iteration, profiles/r02_bf16_kernel_stats_layers.txt): the big-tile variant — full
 // resolution and the first coarse level — is 1.2-2.1x faster than the fp32 kernels except for 4 input channels (one half-empty K
@@ -323,6 +324,9 @@ static bool bf16_pays(const dpi_conv_desc* d, bool flip) {
   const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
   int nr, nh;
   bf16_variant(d, cout, &nr, &nh);
+  // split mode (six MFMAs and three LDS fragments per position): wins 12-48 % over the fp32 kernels when both channel counts are
+  // >= 8 (25<->16, 51<->32, 137<->8, 8<->13), loses with <= 4 channels on either side (64->4: 1.28 vs 0.96 ms)
+  if (d->precision == 2) return nr == 4 && cin >= 8 && cout >= 8;
   return nr == 4 && (cin > 4 || cout > 16);      // 4 -> 8 forward: 217 vs 196 us (fp32); 4 -> 67 (backward-data of 67 -> 4): 888 vs 1056 us
 }
 
