@@ -15,6 +15,11 @@ time per GPU as replayed hipGraphs, K Adam iterations per patch, timed END TO EN
 the K iterations, dpi_overlap_add, the single all-reduce of the accumulator volume and the normalisation.  `--patches P` bounds
 the queue to the first P*N patches (the full 343 x 3000 iterations take hours); value = patch-iterations/s over all ranks.
 
+Workload c4 (BASELINE configs[3] data): the shipped 2-D section datasets/lines (170 x 100; the copy recorded in
+tests/golden/host.npz — /root/reference does not exist on the GPU box) with its random66 mask, default 2-D MulResUnet
+(2 186 704 parameters), the geometry of proof_of_concept_2D.ipynb (3000 iterations in 142 s = 21 it/s on a V100); `--aa-weight W`
+adds the anti-aliasing regulariser (dips + Hale2D adjoint every iteration).
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
 import argparse
@@ -44,7 +49,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"])
+    ap.add_argument("--aa-weight", type=float, default=0.0, help="c4: weight of the anti-aliasing (directional Laplacian) regulariser")
     ap.add_argument("--patch", type=int, nargs=3, default=None)
     ap.add_argument("--upsample", default="linear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -58,7 +64,7 @@ def parse():
     ap.add_argument("--concurrent", type=int, default=6, help="c3: patches optimised side by side on one GPU")
     a = ap.parse_args()
     if a.steps is None:
-        a.steps = 10 if a.workload == "c2" else 100
+        a.steps = {"c2": 10, "c3": 100, "c4": 300}[a.workload]
     if a.patch is None:
         a.patch = [256, 128, 128] if a.workload == "c2" else [64, 64, 64]
     return a
@@ -344,6 +350,72 @@ def run_c3(a, rank, world, device):
             "cpu_baseline": None}
 
 
+def run_c4(a, rank, world, device):
+    """configs[3] data: 2-D MulResUnet on the datasets/lines section; hipGraph loop without the regulariser, eager with it."""
+    from deep_prior_interpolation_amd import utils as u
+    from deep_prior_interpolation_amd.main import Interpolator
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    z = np.load(os.path.join(ROOT, "tests", "golden", "host.npz"))
+    img, mask = z["lines/original"].astype(np.float64), z["lines/mask"].astype(np.float64)
+    argv = ["--imgdir", "lines", "--datadim", "2d", "--net", "multiunet", "--inputdepth", "64", "--upsample", "linear", "--loss", "mae",
+            "--gain", "1", "--epochs", str(a.steps + a.warmup + 2), "--gpu", "0", "--precision", a.precision]
+    if a.aa_weight > 0:
+        argv += ["--aa_weight", str(a.aa_weight)]
+    args = parse_arguments(argv)
+    u.set_seed(rank)
+    T = Interpolator(args, "/tmp", device=device, seed=rank)
+    T.load_data({"image": img, "mask": mask, "name": "0"})
+    T.build_model()
+    T.build_input()
+    T.build_regularizer()
+    from deep_prior_interpolation_amd.optim import FusedAdam
+    T.optimizer = FusedAdam(T.net.parameters(), lr=args.lr)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+    if a.aa_weight > 0:
+        def step():
+            T.optimizer.zero_grad()
+            T.optimization_loop()
+            T.optimizer.step()
+        mode = "eager (regulariser in the loop)"
+    else:
+        graph = T.graph_prepare()
+        step = graph.replay
+        mode = "graph"
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if a.aa_weight <= 0:
+        T.graph_finish()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return None
+    flop_iter, bmin = 6.2e9, 0.278e9                         # BASELINE.md §3: 2-D 170x100 row
+    ms = dt / a.steps * 1e3
+    return {"metric": "Adam iters/sec on 2D MultiRes-UNet per GPU (datasets/lines)", "value": round(world * a.steps / dt, 2), "unit": "it/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if a.precision == "fp32" else a.precision, "data": "datasets/lines section (recorded fixture)",
+            "config": {"workload": "configs[3] data: 2-D MulResUnet defaults (%d params) on datasets/lines 170x100, random66 mask, gain 1, MAE, bilinear, "
+                                   "loop mode %s, aa_weight %g; reference notebook: 21 it/s on a V100 (different hardware, no regulariser)"
+                                   % (T.num_params, mode, a.aa_weight), "last_loss": T.history.loss[-1] if T.history.loss else None},
+            "roofline": {"bound": "launch", "unit": "it/s", "achieved": round(a.steps / dt, 2), "peak": round(1.0 / max(flop_iter / (FP32_PEAK_TFLOPS * 1e12), bmin / (HBM_PEAK_GBS * 1e9)), 1),
+                         "frac": round((a.steps / dt) * max(flop_iter / (FP32_PEAK_TFLOPS * 1e12), bmin / (HBM_PEAK_GBS * 1e9)), 5), "traffic": None,
+                         "note": "17 000 pixels: 6.2 GFLOP and 0.28 GB per iteration (roofline 0.04 ms); the iteration is ~400 dependent launches of a "
+                                 "few microseconds each, i.e. bound by launch / dependency latency, not by a throughput roofline"},
+            "cpu_baseline": None}
+
+
 def main():
     global PRECISION
     a = parse()
@@ -358,7 +430,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
-    out = run_c2(a, rank, world, device) if a.workload == "c2" else run_c3(a, rank, world, device)
+    out = {"c2": run_c2, "c3": run_c3, "c4": run_c4}[a.workload](a, rank, world, device)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
