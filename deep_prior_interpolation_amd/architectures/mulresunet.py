@@ -129,12 +129,6 @@ class SkipConcat(Concat):
             rp = skip[0]
             mods = list(deeper._modules.values())
             if isinstance(rp, ResPath) and rp._fusable() and isinstance(mods[-1], hnn.Upsample):
-                if x.ndim == 5 and x.requires_grad and deeper.fused_head():
-                    # both branches read x: their gradients meet inside the down conv's backward-data (ops.FanIn), not in an aten add
-                    fan = ops.FanIn()
-                    x1, x2 = ops.fork(x)
-                    deep = deeper(x2, stop_before_last=True, fanin=fan)
-                    return ops.skip_join(x1, deep, rp, rp.act.negative_slope, mods[-1].mode, fanin=fan)
                 deep = deeper(x, stop_before_last=True)
                 if deep.ndim == 5:
                     return ops.skip_join(x, deep, rp, rp.act.negative_slope, mods[-1].mode)
@@ -146,24 +140,16 @@ class DownPath(Seq):
     """The `deeper` branch: stride-2 conv [-> BN] -> act -> dropout -> block -> [inner] -> upsample.  Same children and
     names as a plain Seq; only the conv -> BN -> LeakyReLU head (3-D) is executed as one fused op."""
 
-    def forward(self, x, stop_before_last=False, fanin=None):
+    def forward(self, x, stop_before_last=False):
         mods = list(self._modules.values())
-        return self._run(mods[:-1] if stop_before_last else mods, x, fanin)
+        return self._run(mods[:-1] if stop_before_last else mods, x)
 
-    @staticmethod
-    def _has_fused_head(mods):
-        return (len(mods) >= 3 and isinstance(mods[1], (hnn.BatchNorm3d, hnn.BatchNorm2d)) and isinstance(mods[2], hnn.LeakyReLU)
-                and isinstance(mods[0], nn.Sequential))
-
-    def fused_head(self):
-        """True when the branch starts with conv -> BN -> LeakyReLU executed as one ConvBnActFn node (the 3-D net)."""
-        return self._has_fused_head(list(self._modules.values()))
-
-    def _run(self, mods, x, fanin=None):
-        if self._has_fused_head(mods):
+    def _run(self, mods, x):
+        if (len(mods) >= 3 and isinstance(mods[1], (hnn.BatchNorm3d, hnn.BatchNorm2d)) and isinstance(mods[2], hnn.LeakyReLU)
+                and isinstance(mods[0], nn.Sequential)):
             conv_m, bn, act = mods[0][0], mods[1], mods[2]
             x = ops.conv_bn_act(x, conv_m.weight, conv_m.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                bn.num_batches_tracked, conv_m._s, act.negative_slope, fanin=fanin)
+                                bn.num_batches_tracked, conv_m._s, act.negative_slope)
             mods = mods[3:]
         for m in mods:
             x = m(x)

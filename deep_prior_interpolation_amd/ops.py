@@ -421,9 +421,8 @@ class ConvBnActFn(torch.autograd.Function):
     The conv bias feeds a BatchNorm, so its gradient is analytically zero and returned as zeros."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, stride, slope, fanin=None):
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, stride, slope):
         x, w = _req(x, "conv input"), _req(w, "conv weight")
-        ctx.fanin = fanin
         d = make_desc(x, w, stride)
         Do, Ho, Wo = desc_out_dims(d)
         L = _lib.load()
@@ -451,16 +450,12 @@ class ConvBnActFn(torch.autograd.Function):
             dw = torch.empty_like(w)
             conv_bwd_weight_async(d, x, None, dr, dw)
         if ctx.needs_input_grad[0]:
-            buf = ctx.fanin.take(x) if ctx.fanin is not None else None
-            if buf is not None:
-                raw_conv_bwd_data(d, dr, w, buf, accumulate=True)      # gradient fan-in: add into the other branch's gradient (see FanIn)
-            else:
-                dx = torch.empty_like(x)
-                raw_conv_bwd_data(d, dr, w, dx)
+            dx = torch.empty_like(x)
+            raw_conv_bwd_data(d, dr, w, dx)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _zeros_like_or_none(ctx.bias_ref)
         join_weight_grads()
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None
 
 
 def _cba_raw(d, x, in_chain, w, b, bn, slope, r_out, mi_out, chain_out):
@@ -480,42 +475,6 @@ def _zeros_like_or_none(b):
     update of a zero gradient is exactly 0, so the trajectory is the same).  Handing out cached zero tensors instead made
     autograd clone each of them every iteration (48 device-to-device copies)."""
     return None
-
-
-class FanIn:
-    """Gradient fan-in of a tensor that feeds two branches of ONE level (the skip branch and the stride-2 down conv of the deeper
-    branch both read the encoder block's output): autograd would compute the two gradients separately and add them (an aten add
-    pass over the full-resolution tensor, 3 tensor passes).  Here the branch whose backward runs first (SkipJoinFn: the deeper
-    branch's backward cannot start before it has produced d(deep)) deposits its freshly written gradient buffer, and the later
-    one (ConvBnActFn of the down conv) accumulates into it inside its backward-data epilogue and reports no gradient of its own;
-    ForkFn.backward then simply forwards the deposited buffer.  The order is a data dependency, not a scheduling assumption."""
-
-    def __init__(self):
-        self.buf = None
-
-    def deposit(self, dx):
-        self.buf = dx
-
-    def take(self, like):
-        b, self.buf = self.buf, None
-        return b if (b is not None and b.shape == like.shape) else None
-
-
-class ForkFn(torch.autograd.Function):
-    """x -> (x, x) for the two consumers of a FanIn; backward: the sum of the two gradients (one of them usually None because
-    its producer already accumulated into the other)."""
-
-    @staticmethod
-    def forward(ctx, x):
-        return x.view_as(x), x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, g1, g2):
-        if g1 is None:
-            return g2
-        if g2 is None:
-            return g1
-        return add(g1, g2)
 
 
 class Block3dFn(torch.autograd.Function):
@@ -693,9 +652,8 @@ class SkipJoinFn(torch.autograd.Function):
     of d(cat) to the ResPath backward and the up-sampling adjoint."""
 
     @staticmethod
-    def forward(ctx, x, deep, rp, slope, linear, fanin, *p):
+    def forward(ctx, x, deep, rp, slope, linear, *p):
         x, deep = _req(x, "skip input"), _req(deep, "deep input")
-        ctx.fanin = fanin
         (w3, b3, g3, e3, w1, b1, g1, e1, gB, eB) = p
         L = _lib.load()
         f32 = dict(dtype=torch.float32, device=x.device)
@@ -759,11 +717,9 @@ class SkipJoinFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             raw_conv_bwd_data(d1, dr1, w1, dx)
             raw_conv_bwd_data(d3, dr3, w3, dx, accumulate=True)
-            if ctx.fanin is not None:
-                ctx.fanin.deposit(dx)            # the down conv of the deeper branch adds its gradient into this buffer
         join_weight_grads()
         z = _zeros_like_or_none
-        return dx, ddeep, None, None, None, None, dw3, z(b3), dg3, de3, dw1, z(b1), dg1, de1, dgB, deB
+        return dx, ddeep, None, None, None, dw3, z(b3), dg3, de3, dw1, z(b1), dg1, de1, dgB, deB
 
 
 class LeakyReLUFn(torch.autograd.Function):
@@ -1019,12 +975,8 @@ def batch_norm(x, gamma, beta, running_mean=None, running_var=None, nbt=None, sl
     return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, nbt, float(slope), float(pre_slope))
 
 
-def conv_bn_act(x, w, b, gamma, beta, running_mean, running_var, nbt, stride=1, slope=0.2, fanin=None):
-    return ConvBnActFn.apply(x, w, b, gamma, beta, running_mean, running_var, nbt, int(stride), float(slope), fanin)
-
-
-def fork(x):
-    return ForkFn.apply(x)
+def conv_bn_act(x, w, b, gamma, beta, running_mean, running_var, nbt, stride=1, slope=0.2):
+    return ConvBnActFn.apply(x, w, b, gamma, beta, running_mean, running_var, nbt, int(stride), float(slope))
 
 
 def _cba_params(m):
@@ -1044,10 +996,10 @@ def respath3d(x, rp, slope):
     return ResPath3dFn.apply(x, rp, slope, *p)
 
 
-def skip_join(x, deep, rp, slope, mode, fanin=None):
+def skip_join(x, deep, rp, slope, mode):
     """cat[ResPath3d(x), Upsample(deep)] written in place (zero-copy concat)."""
     p = _cba_params(rp.conv3x3) + _cba_params(rp.conv1x1) + [rp.bn.weight, rp.bn.bias]
-    return SkipJoinFn.apply(x, deep, rp, slope, mode != "nearest", fanin, *p)
+    return SkipJoinFn.apply(x, deep, rp, slope, mode != "nearest", *p)
 
 
 def leaky_relu(x, slope=0.2):
