@@ -984,7 +984,7 @@ static bool mfma_bw_swap_better(const dpi_conv_desc* d) {
 }
 
 static int g_bw_want = 2304;        // tuning knobs (dpi_set_bw_tuning): workgroups aimed at, XCD-aware workgroup order on/off
-static int g_bw_xcd_order = 1;
+static int g_bw_xcd_order = getenv("DPI_BW_XCD_ORDER") ? atoi(getenv("DPI_BW_XCD_ORDER")) : 1;   // env: A/B runs of the whole iteration
 extern "C" void dpi_set_bw_tuning(int want_workgroups, int xcd_order) {
   if (want_workgroups > 0) g_bw_want = want_workgroups;
   if (xcd_order >= 0) g_bw_xcd_order = xcd_order;
