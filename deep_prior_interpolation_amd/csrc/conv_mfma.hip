@@ -983,7 +983,7 @@ static bool mfma_bw_swap_better(const dpi_conv_desc* d) {
   return util(d->Cin, d->Cout) > 1.15 * util(d->Cout, d->Cin);
 }
 
-static int g_bw_want = 2304;        // tuning knobs (dpi_set_bw_tuning): workgroups aimed at, XCD-aware workgroup order on/off
+static int g_bw_want = getenv("DPI_BW_WANT") ? atoi(getenv("DPI_BW_WANT")) : 2304;        // tuning knobs (dpi_set_bw_tuning): workgroups aimed at, XCD-aware workgroup order on/off
 // XCD-aware (chunk, group) order: OFF by default.  Isolated launches gain 4-6 % (25 -> 16: 1.187 -> 1.136 ms), but inside the
 // iteration (weight gradients on the side stream next to the backward-data / BatchNorm chain) it LOSES: 37.2-37.4 vs 36.6-36.8 ms
 // per iteration in an A/B of four bench runs (round 2).  DPI_BW_XCD_ORDER=1 / dpi_set_bw_tuning switch it on for experiments.
