@@ -546,3 +546,28 @@ def test_conv_split_mode_has_fp32_accuracy(ops, cin, cout, shape, k, monkeypatch
         errs[prec] = (rel(y, yr), rel(dx, xr.grad))
     assert errs[2][0] < 2e-6 and errs[2][1] < 2e-6, errs
     assert errs[2][0] < 4 * errs[0][0] + 1e-7 and errs[2][1] < 4 * errs[0][1] + 1e-7, errs
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(25, 1, (32, 32, 40)), (25, 8, (16, 32, 64)), (64, 4, (16, 48, 64)), (51, 17, (12, 16, 40)), (13, 4, (33, 31, 37)),
+                                            (9, 20, (8, 16, 32))])
+def test_conv_bwd_weight_with_input_chain(ops, cin, cout, shape):
+    """dW when the conv input is T(x) — a raw conv output with a pending BatchNorm + LeakyReLU chain — for every kernel family,
+    including the swapped MFMA orientation (few output channels), where the chain is applied to the A-operand rows."""
+    gen = torch.Generator().manual_seed(cin * 77 + cout)
+    x = torch.randn((1, cin) + shape, generator=gen)
+    dy = torch.randn((1, cout) + shape, generator=gen)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen) * 0.1
+    chain = torch.stack([1.0 + 0.3 * torch.randn(cin, generator=gen), 0.2 * torch.randn(cin, generator=gen), torch.full((cin,), 0.2),
+                         1.0 + 0.3 * torch.randn(cin, generator=gen), 0.2 * torch.randn(cin, generator=gen)], dim=1).contiguous()
+    xg, cg = x.to(DEV), chain.to(DEV)
+    tx = torch.empty_like(xg)
+    ops.raw_chain_apply(xg, cg, cin, xg.numel() // cin, tx)
+    wr = w.double().requires_grad_(True)
+    O.conv_nd(tx.cpu().double(), wr, None, 1).backward(dy.double())
+    d = ops.make_desc(xg, w.to(DEV), 1)
+    dw = torch.empty_like(w, device=DEV)
+    ops.raw_conv_bwd_weight(d, xg, cg, dy.to(DEV), dw)
+    assert rel(dw, wr.grad) < 5e-6
+    dw2 = torch.empty_like(dw)
+    ops.raw_conv_bwd_weight(d, tx, None, dy.to(DEV), dw2)                 # same thing with the chain materialised first
+    assert rel(dw, dw2) < 2e-6
