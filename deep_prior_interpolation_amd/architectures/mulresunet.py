@@ -16,7 +16,6 @@ __all__ = ["MulResUnet", "MulResUnet3D", "MultiResBlock", "ResPath", "multires_w
 
 
 FUSE_BLOCKS = True     # run Block3d / ResPath3d as single fused autograd nodes (ops.Block3dFn / ops.ResPath3dFn)
-LAZY_CHAINS = True     # ... and let them hand raw tensors + pending BN/activation chains to their consumers (ops.pending_chain)
 
 
 def multires_widths(U, alpha=1.67):
@@ -53,11 +52,9 @@ class MultiResBlock(nn.Module):
                 and all(isinstance(m._parts()[2], hnn.LeakyReLU) and m._parts()[2].negative_slope == self.act.negative_slope
                         for m in (self.conv3x3, self.conv5x5, self.conv7x7, self.shortcut)))
 
-    lazy_out = False      # set by the 3-D net builder: hand the consumer (t, pending chain) instead of the materialised output
-
     def forward(self, x):
         if FUSE_BLOCKS and self._fusable():
-            return ops.block3d(x, self, self.act.negative_slope, lazy=self.lazy_out and LAZY_CHAINS)
+            return ops.block3d(x, self, self.act.negative_slope)
         o1 = self.conv3x3(x)
         o2 = self.conv5x5(o1)
         o3 = self.conv7x7(o2)
@@ -143,8 +140,6 @@ class DownPath(Seq):
     """The `deeper` branch: stride-2 conv [-> BN] -> act -> dropout -> block -> [inner] -> upsample.  Same children and
     names as a plain Seq; only the conv -> BN -> LeakyReLU head (3-D) is executed as one fused op."""
 
-    lazy_out = False      # set by the 3-D net builder (see MultiResBlock.lazy_out)
-
     def forward(self, x, stop_before_last=False):
         mods = list(self._modules.values())
         return self._run(mods[:-1] if stop_before_last else mods, x)
@@ -154,7 +149,7 @@ class DownPath(Seq):
                 and isinstance(mods[0], nn.Sequential)):
             conv_m, bn, act = mods[0][0], mods[1], mods[2]
             x = ops.conv_bn_act(x, conv_m.weight, conv_m.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                bn.num_batches_tracked, conv_m._s, act.negative_slope, lazy=self.lazy_out and LAZY_CHAINS and FUSE_BLOCKS)
+                                bn.num_batches_tracked, conv_m._s, act.negative_slope)
             mods = mods[3:]
         for m in mods:
             x = m(x)
@@ -196,12 +191,6 @@ def _mulresunet(nd, num_input_channels, num_output_channels, num_channels_down, 
                               need_bias, dropout))
         depth = block.out_dim
         cur = inner
-    if nd == 3:
-        # every consumer of a block / down-conv output inside this net is chain-aware (convolutions, up-sampling) or materialises
-        # on entry (ops._req): let the fused nodes skip writing their BatchNorm + activation output
-        for m in model.modules():
-            if isinstance(m, (MultiResBlock, DownPath)):
-                m.lazy_out = True
     last = sum(multires_widths(num_channels_up[0], alpha))
     model.add(conv_nd(nd, last, num_output_channels, 3 if nd == 3 else 1, bias=need_bias))
     if isinstance(last_act_fun, str) and last_act_fun.lower() == "none":

@@ -16,29 +16,7 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
-# ---- pending chains -------------------------------------------------------------------------------------------------
-# A fused node of the 3-D net may hand its consumer the RAW tensor t together with the per-channel chain T of its trailing
-# BatchNorm + LeakyReLU instead of materialising y = T(t) (one read + one write of the tensor per block saved): the chain
-# travels as the attribute `_dpi_chain` of the tensor object and every chain-aware consumer (convolutions, up-sampling) applies
-# it while loading.  Convention: such a tensor STANDS FOR y — the gradient that flows back to it is dL/dy, exactly what the
-# producer's backward expects — so a consumer that is not chain-aware may simply materialise it first (`_req` does that for
-# every op in this file), with no autograd bookkeeping.  Only modules flagged `lazy_out` by the net builder produce them; a
-# block used on its own returns a materialised tensor.
-def pending_chain(t):
-    return getattr(t, "_dpi_chain", None)
-
-
-def _with_chain(t, chain):
-    t._dpi_chain = chain
-    return t
-
-
-def _req(t, name, keep_chain=False):
-    ch = getattr(t, "_dpi_chain", None)
-    if ch is not None and not keep_chain:
-        y = torch.empty_like(t)
-        raw_chain_apply(t, ch, t.shape[1], t.numel() // t.shape[1], y)
-        t = y
+def _req(t, name):
     if not t.is_cuda:
         raise _lib.DpiError("%s must live on the GPU: the HIP path has no CPU fallback" % name)
     if t.dtype != torch.float32:
@@ -283,15 +261,15 @@ class ConvFn(torch.autograd.Function):
     """nn.Conv3d / nn.Conv2d, k in {1,3}, stride in {1,2}, zero pad (k-1)//2 (reference base.py:123,176)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, xch=None):
-        x, w = _req(x, "conv input", keep_chain=True), _req(w, "conv weight")
+    def forward(ctx, x, w, b, stride):
+        x, w = _req(x, "conv input"), _req(w, "conv weight")
         b = _req(b, "conv bias") if b is not None else None
         d = make_desc(x, w, stride)
         Do, Ho, Wo = desc_out_dims(d)
         y = torch.empty(_like_spatial(x, d.Cout, Do, Ho, Wo), dtype=torch.float32, device=x.device)
-        raw_conv_fwd(d, x, xch, w, b, y)
+        raw_conv_fwd(d, x, None, w, b, y)
         ctx.save_for_backward(x, w)
-        ctx.d, ctx.xch = d, xch
+        ctx.d = d
         ctx.has_bias = b is not None
         return y
 
@@ -303,7 +281,7 @@ class ConvFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            conv_bwd_weight_async(d, x, ctx.xch, dy, dw)
+            conv_bwd_weight_async(d, x, None, dy, dw)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             raw_conv_bwd_data(d, dy, w, dx)
@@ -311,7 +289,7 @@ class ConvFn(torch.autograd.Function):
             db = torch.empty(d.Cout, dtype=torch.float32, device=x.device)
             raw_channel_sum(dy, d.Cout, dy.numel() // d.Cout, db)
         join_weight_grads()
-        return dx, dw, db, None, None
+        return dx, dw, db, None
 
 
 def _bn_backward(dy, x, mi, gamma, beta, pre_slope, post_slope, in_chain=None, dx=None):
@@ -443,44 +421,41 @@ class ConvBnActFn(torch.autograd.Function):
     The conv bias feeds a BatchNorm, so its gradient is analytically zero and returned as zeros."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, stride, slope, xch=None, lazy=False):
-        x, w = _req(x, "conv input", keep_chain=True), _req(w, "conv weight")
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, stride, slope):
+        x, w = _req(x, "conv input"), _req(w, "conv weight")
         d = make_desc(x, w, stride)
         Do, Ho, Wo = desc_out_dims(d)
         L = _lib.load()
         r = torch.empty(_like_spatial(x, d.Cout, Do, Ho, Wo), dtype=torch.float32, device=x.device)
         nblk = L.dpi_conv_fwd_stat_blocks(C.byref(d))
         part = torch.empty(nblk * d.Cout * 2, dtype=torch.float64, device=x.device)
-        raw_conv_fwd(d, x, xch, w, b, r, part)
+        raw_conv_fwd(d, x, None, w, b, r, part)
         V = Do * Ho * Wo
         mi = torch.empty(2 * d.Cout, dtype=torch.float32, device=x.device)
         chain = torch.empty(d.Cout * 5, dtype=torch.float32, device=x.device)
         raw_bn_finalize(part, nblk, d.Cout, V, gamma, beta, slope, running_mean, running_var, nbt, mi, chain)
-        ctx.save_for_backward(x, w, r, gamma, beta, mi)
-        ctx.d, ctx.slope, ctx.has_bias, ctx.bias_ref, ctx.xch = d, float(slope), b is not None, b, xch
-        ctx.mark_non_differentiable(chain)
-        if lazy:                                        # the consumer applies BN + activation while loading (pending chain)
-            return r.view_as(r), chain
         y = torch.empty_like(r)
         raw_chain_apply(r, chain, d.Cout, V, y)
-        return y, chain
+        ctx.save_for_backward(x, w, r, gamma, beta, mi)
+        ctx.d, ctx.slope, ctx.has_bias, ctx.bias_ref = d, float(slope), b is not None, b
+        return y
 
     @staticmethod
-    def backward(ctx, dy, _dchain):
+    def backward(ctx, dy):
         x, w, r, gamma, beta, mi = ctx.saved_tensors
         d = ctx.d
         dr, dgamma, dbeta = _bn_backward(_req(dy, "conv-bn-act grad"), r, mi, gamma, beta, 1.0, ctx.slope)
         dx = dw = db = None
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            conv_bwd_weight_async(d, x, ctx.xch, dr, dw)
+            conv_bwd_weight_async(d, x, None, dr, dw)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             raw_conv_bwd_data(d, dr, w, dx)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _zeros_like_or_none(ctx.bias_ref)
         join_weight_grads()
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None
 
 
 def _cba_raw(d, x, in_chain, w, b, bn, slope, r_out, mi_out, chain_out):
@@ -512,8 +487,8 @@ class Block3dFn(torch.autograd.Function):
     Elementwise traffic per block: 6 tensor passes forward instead of 15 (in units of out_dim x V floats)."""
 
     @staticmethod
-    def forward(ctx, x, xch, lazy, blk, slope, *p):
-        x = _req(x, "block input", keep_chain=True)
+    def forward(ctx, x, blk, slope, *p):
+        x = _req(x, "block input")
         (w1, b1, g1, e1, w2, b2, g2, e2, w3, b3, g3, e3, ws, bs, gs, es, gA, eA, gB, eB) = p
         L = _lib.load()
         dev = x.device
@@ -530,7 +505,7 @@ class Block3dFn(torch.autograd.Function):
         ch1, ch2, ch3 = CH[:c1 * 5], CH[c1 * 5:(c1 + c2) * 5], CH[(c1 + c2) * 5:]
         mi1, mi2, mi3 = (torch.empty(2 * c, **f32) for c in (c1, c2, c3))
         miA, miS, miB = (torch.empty(2 * Ct, **f32) for _ in range(3))
-        _cba_raw(d1, x, xch, w1, b1, bn1_, slope, r1, mi1, ch1)
+        _cba_raw(d1, x, None, w1, b1, bn1_, slope, r1, mi1, ch1)
         d2 = make_desc(r1, w2, 1)
         _cba_raw(d2, r1, ch1, w2, b2, bn2_, slope, r2, mi2, ch2)
         d3 = make_desc(r2, w3, 1)
@@ -543,7 +518,7 @@ class Block3dFn(torch.autograd.Function):
         dsc = make_desc(x, ws, 1)
         S = torch.empty_like(R)
         chS = torch.empty(Ct * 5, **f32)
-        _cba_raw(dsc, x, xch, ws, bs, bns_, slope, S, miS, chS)
+        _cba_raw(dsc, x, None, ws, bs, bns_, slope, S, miS, chS)
         # residual join + statistics of act(t) for bn2
         t = torch.empty_like(R)
         nblk = L.dpi_stat_blocks(Ct, V)
@@ -554,21 +529,17 @@ class Block3dFn(torch.autograd.Function):
         B = blk.bn2
         raw_bn_finalize(part, nblk, Ct, V, gB, eB, slope, B.running_mean, B.running_var, B.num_batches_tracked, miB, chB,
                         act_first=1)
+        y = torch.empty_like(R)
+        raw_chain_apply(t, chB, Ct, V, y)
         ctx.save_for_backward(x, R, S, t, CH, mi1, mi2, mi3, miA, miS, miB, *[q for q in p if q is not None])
         ctx.none_mask = [q is None for q in p]
         ctx.descs = (d1, d2, d3, dsc)
         ctx.slope = float(slope)
         ctx.split = (c1, c2, c3)
-        ctx.xch = xch
-        ctx.mark_non_differentiable(chB)
-        if lazy:                                        # hand (t, bn2 o act) to the consumer instead of writing y (pending chain)
-            return t.view_as(t), chB
-        y = torch.empty_like(R)
-        raw_chain_apply(t, chB, Ct, V, y)
-        return y, chB
+        return y
 
     @staticmethod
-    def backward(ctx, dy, _dchain):
+    def backward(ctx, dy):
         dy = _req(dy, "block grad")
         x, R, S, t, CH, mi1, mi2, mi3, miA, miS, miB = ctx.saved_tensors[:11]
         it = iter(ctx.saved_tensors[11:])
@@ -598,9 +569,9 @@ class Block3dFn(torch.autograd.Function):
         raw_conv_bwd_data(d2, dR[:, s2], w2, dcat[:, s1], accumulate=True)
         _, dg1, de1 = _bn_backward(dcat[:, s1], R[:, s1], mi1, g1, e1, 1.0, slope, dx=dR[:, s1])
         dw1 = torch.empty_like(w1)
-        conv_bwd_weight_async(d1, x, ctx.xch, dR[:, s1], dw1)
+        conv_bwd_weight_async(d1, x, None, dR[:, s1], dw1)
         dws = torch.empty_like(ws)
-        conv_bwd_weight_async(dsc, x, ctx.xch, dS, dws)
+        conv_bwd_weight_async(dsc, x, None, dS, dws)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -608,7 +579,7 @@ class Block3dFn(torch.autograd.Function):
             raw_conv_bwd_data(d1, dR[:, s1], w1, dx, accumulate=True)
         join_weight_grads()
         z = _zeros_like_or_none      # conv biases feed a BatchNorm: analytically zero gradient
-        return (dx, None, None, None, None, dw1, z(b1), dg1, de1, dw2, z(b2), dg2, de2, dw3, z(b3), dg3, de3, dws, z(bs), dgs, des,
+        return (dx, None, None, dw1, z(b1), dg1, de1, dw2, z(b2), dg2, de2, dw3, z(b3), dg3, de3, dws, z(bs), dgs, des,
                 dgA, deA, dgB, deB)
 
 
@@ -681,9 +652,8 @@ class SkipJoinFn(torch.autograd.Function):
     of d(cat) to the ResPath backward and the up-sampling adjoint."""
 
     @staticmethod
-    def forward(ctx, x, xch, deep, dch, rp, slope, linear, *p):
-        x, deep = _req(x, "skip input", keep_chain=True), _req(deep, "deep input", keep_chain=True)
-        ctx.xch = xch
+    def forward(ctx, x, deep, rp, slope, linear, *p):
+        x, deep = _req(x, "skip input"), _req(deep, "deep input")
         (w3, b3, g3, e3, w1, b1, g1, e1, gB, eB) = p
         L = _lib.load()
         f32 = dict(dtype=torch.float32, device=x.device)
@@ -699,8 +669,8 @@ class SkipJoinFn(torch.autograd.Function):
         r1 = torch.empty_like(r3)
         mi3, mi1, miB = (torch.empty(2 * Cs, **f32) for _ in range(3))
         ch3, ch1, chB = (torch.empty(5 * Cs, **f32) for _ in range(3))
-        _cba_raw(d3, x, xch, w3, b3, bn3_, slope, r3, mi3, ch3)
-        _cba_raw(d1, x, xch, w1, b1, bn1_, slope, r1, mi1, ch1)
+        _cba_raw(d3, x, None, w3, b3, bn3_, slope, r3, mi3, ch3)
+        _cba_raw(d1, x, None, w1, b1, bn1_, slope, r1, mi1, ch1)
         t = torch.empty_like(r3)
         nblk = L.dpi_stat_blocks(Cs, V)
         part = torch.empty(nblk * Cs * 2, dtype=torch.float64, device=x.device)
@@ -711,7 +681,7 @@ class SkipJoinFn(torch.autograd.Function):
                         act_first=1)
         cat = torch.empty(_like_spatial(x, Cs + Cd, Do, Ho, Wo), **f32)
         raw_chain_apply(t, chB, Cs, V, cat[:, :Cs])
-        check(L.dpi_upsample2x_fwd(ptr(deep), ptr(dch), Cd, Dd, Hd, Wd, Do, Ho, Wo, int(linear), ptr(cat[:, Cs:]), stream()),
+        check(L.dpi_upsample2x_fwd(ptr(deep), None, Cd, Dd, Hd, Wd, Do, Ho, Wo, int(linear), ptr(cat[:, Cs:]), stream()),
               "dpi_upsample2x_fwd")
         ctx.save_for_backward(x, r3, r1, t, mi3, mi1, miB, *[q for q in p if q is not None])
         ctx.none_mask = [q is None for q in p]
@@ -731,7 +701,7 @@ class SkipJoinFn(torch.autograd.Function):
         Cs, Cd, Dd, Hd, Wd, Do, Ho, Wo, linear, deep_shape = ctx.up
         L = _lib.load()
         ddeep = None
-        if ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[1]:
             ddeep = torch.empty(deep_shape, dtype=torch.float32, device=dcat.device)
             raw_upsample2x_bwd(dcat[:, Cs:], Cd, Dd, Hd, Wd, Do, Ho, Wo, linear, ddeep)
         dt, dgB, deB, (red3, red1) = _bn_backward_fork(dcat[:, :Cs], t, miB, gB, eB, slope, 1.0,
@@ -740,8 +710,8 @@ class SkipJoinFn(torch.autograd.Function):
                                                                      (r1, mi1, g1, e1, None, slope, red1))
         del dt
         dw3, dw1 = torch.empty_like(w3), torch.empty_like(w1)
-        conv_bwd_weight_async(d3, x, ctx.xch, dr3, dw3)
-        conv_bwd_weight_async(d1, x, ctx.xch, dr1, dw1)
+        conv_bwd_weight_async(d3, x, None, dr3, dw3)
+        conv_bwd_weight_async(d1, x, None, dr1, dw1)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -749,7 +719,7 @@ class SkipJoinFn(torch.autograd.Function):
             raw_conv_bwd_data(d3, dr3, w3, dx, accumulate=True)
         join_weight_grads()
         z = _zeros_like_or_none
-        return dx, None, ddeep, None, None, None, None, dw3, z(b3), dg3, de3, dw1, z(b1), dg1, de1, dgB, deB
+        return dx, ddeep, None, None, None, dw3, z(b3), dg3, de3, dw1, z(b1), dg1, de1, dgB, deB
 
 
 class LeakyReLUFn(torch.autograd.Function):
@@ -990,7 +960,7 @@ class Deconv4x4s2Fn(torch.autograd.Function):
 
 
 def conv(x, w, b, stride=1):
-    return ConvFn.apply(x, w, b, stride, pending_chain(x))
+    return ConvFn.apply(x, w, b, stride)
 
 
 def max_pool2x2(x):
@@ -1005,10 +975,8 @@ def batch_norm(x, gamma, beta, running_mean=None, running_var=None, nbt=None, sl
     return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, nbt, float(slope), float(pre_slope))
 
 
-def conv_bn_act(x, w, b, gamma, beta, running_mean, running_var, nbt, stride=1, slope=0.2, lazy=False):
-    y, chain = ConvBnActFn.apply(x, w, b, gamma, beta, running_mean, running_var, nbt, int(stride), float(slope), pending_chain(x),
-                                 bool(lazy))
-    return _with_chain(y, chain) if lazy else y
+def conv_bn_act(x, w, b, gamma, beta, running_mean, running_var, nbt, stride=1, slope=0.2):
+    return ConvBnActFn.apply(x, w, b, gamma, beta, running_mean, running_var, nbt, int(stride), float(slope))
 
 
 def _cba_params(m):
@@ -1016,13 +984,11 @@ def _cba_params(m):
     return [conv_m.weight, conv_m.bias, bn.weight, bn.bias]
 
 
-def block3d(x, blk, slope, lazy=False):
-    """fused Block3d; `blk` is the MultiResBlock module (parameters are passed explicitly so autograd tracks them).
-    lazy: return the raw join tensor with the bn2 o activation chain pending instead of the materialised output."""
+def block3d(x, blk, slope):
+    """fused Block3d; `blk` is the MultiResBlock module (parameters are passed explicitly so autograd tracks them)."""
     p = (_cba_params(blk.conv3x3) + _cba_params(blk.conv5x5) + _cba_params(blk.conv7x7) + _cba_params(blk.shortcut)
          + [blk.bn1.weight, blk.bn1.bias, blk.bn2.weight, blk.bn2.bias])
-    y, chain = Block3dFn.apply(x, pending_chain(x), bool(lazy), blk, slope, *p)
-    return _with_chain(y, chain) if lazy else y
+    return Block3dFn.apply(x, blk, slope, *p)
 
 
 def respath3d(x, rp, slope):
@@ -1033,7 +999,7 @@ def respath3d(x, rp, slope):
 def skip_join(x, deep, rp, slope, mode):
     """cat[ResPath3d(x), Upsample(deep)] written in place (zero-copy concat)."""
     p = _cba_params(rp.conv3x3) + _cba_params(rp.conv1x1) + [rp.bn.weight, rp.bn.bias]
-    return SkipJoinFn.apply(x, pending_chain(x), deep, pending_chain(deep), rp, slope, mode != "nearest", *p)
+    return SkipJoinFn.apply(x, deep, rp, slope, mode != "nearest", *p)
 
 
 def leaky_relu(x, slope=0.2):
