@@ -60,13 +60,16 @@ struct GeoB {
   static constexpr int WE = (NTG * 64 * 8 + 255) / 256;          // weight elements each thread converts per channel group
 };
 
-// round-to-nearest-even fp32 -> bf16 (the rounding torch.Tensor.bfloat16() applies), two values packed into one dword
-__device__ __forceinline__ unsigned bf16_bits(float f) {
-  unsigned u = __builtin_bit_cast(unsigned, f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return u >> 16;
+// round-to-nearest-even fp32 -> bf16 (the rounding torch.Tensor.bfloat16() applies), two values packed into one dword by ONE
+// v_cvt_pk_bf16_f32 (the integer formulation u + 0x7fff + lsb costs 4-5 VALU operations per value, and the staging path of this
+// kernel is VALU-bound in split mode)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) { return bf16_bits(lo) | (bf16_bits(hi) << 16); }
+__device__ __forceinline__ unsigned bf16_bits(float f) { return pack_bf16(f, 0.f) & 0xffffu; }
 
 __device__ __forceinline__ int xcd_tile_b(int bid, int ntiles) {        // contiguous tile range per XCD (see conv_mfma.hip)
   const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, i = bid >> 3;
@@ -80,6 +83,14 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
   m = bf16_bits(r1);
   const float r2 = r1 - __builtin_bit_cast(float, m << 16);
   l = bf16_bits(r2);
+}
+// ... of two values at once, each term already packed (lo | hi << 16): 3 conversions + 4 subtractions + 4 mask / shift operations
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = pack_bf16(x0, x1);
+  const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = pack_bf16(r0, r1);
+  const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+  l = pack_bf16(s0, s1);
 }
 
 template <int KD, int NR, int NH, bool FLIP, int NS = 1>
@@ -189,12 +200,12 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
             *reinterpret_cast<u32x4*>(xl + idx * 4) = (u32x4){pack_bf16(sr[0][e], sr[1][e]), pack_bf16(sr[2][e], sr[3][e]),
                                                               pack_bf16(sr[4][e], sr[5][e]), pack_bf16(sr[6][e], sr[7][e])};
           } else {
-            unsigned h[8], m[8], l[8];
+            unsigned h[4], m[4], l[4];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) split3(sr[c][e], h[c], m[c], l[c]);
-            *reinterpret_cast<u32x4*>(xl + idx * 4) = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-            *reinterpret_cast<u32x4*>(xl + XW + idx * 4) = (u32x4){m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16)};
-            *reinterpret_cast<u32x4*>(xl + 2 * XW + idx * 4) = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+            for (int c = 0; c < 4; ++c) split3_pair(sr[2 * c][e], sr[2 * c + 1][e], h[c], m[c], l[c]);
+            *reinterpret_cast<u32x4*>(xl + idx * 4) = (u32x4){h[0], h[1], h[2], h[3]};
+            *reinterpret_cast<u32x4*>(xl + XW + idx * 4) = (u32x4){m[0], m[1], m[2], m[3]};
+            *reinterpret_cast<u32x4*>(xl + 2 * XW + idx * 4) = (u32x4){l[0], l[1], l[2], l[3]};
           }
         }
       }
