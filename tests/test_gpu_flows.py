@@ -214,3 +214,19 @@ def test_respath_dropout_order(monkeypatch):
         tail = [o for o in order if o in ("bn", "dr")][-2:]
         assert tail == (["bn", "dr"] if nd == 3 else ["dr", "bn"]), (nd, order)
         assert order.count("dr") == 1
+
+
+def test_main_pocs_cli_writes_reference_result_layout(tmp_path, monkeypatch):
+    """python -m deep_prior_interpolation_amd.main_pocs <flags>: same result-file layout as the reference's main_pocs.py
+    (main_pocs.py:262-275: the `_run.npy` dict carries the last POCS projection under 'pocs', history is a HistoryReg)."""
+    from deep_prior_interpolation_amd import main_pocs, utils as u
+    common = _survey(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    main_pocs.main(common + ["--epochs", "4", "--outdir", "pocs", "--pocs_alpha", "0.2", "--pocs_thresh", "10"])
+    files = sorted(f for f in os.listdir("results/pocs") if f.endswith("_run.npy"))
+    assert files == ["0_run.npy", "1_run.npy"]
+    r = np.load("results/pocs/0_run.npy", allow_pickle=True).item()
+    assert set(r) >= {"device", "elapsed", "outpath", "history", "mask", "image", "output", "noise", "pocs"}
+    assert isinstance(r["history"], u.HistoryReg) and len(r["history"]) == 4 and np.isfinite(r["history"].reg).all()
+    assert r["pocs"].shape == (1, 16, 16, 16) and r["output"].shape == (16, 16, 16)
+    assert os.path.exists("results/pocs/args.txt")
