@@ -230,3 +230,27 @@ def test_main_pocs_cli_writes_reference_result_layout(tmp_path, monkeypatch):
     assert isinstance(r["history"], u.HistoryReg) and len(r["history"]) == 4 and np.isfinite(r["history"].reg).all()
     assert r["pocs"].shape == (1, 16, 16, 16) and r["output"].shape == (16, 16, 16)
     assert os.path.exists("results/pocs/args.txt")
+
+
+def test_antialiasing_addon_on_25d_slabs(golden):
+    """configs[3] as stated: --datadim 2.5d (slices of the lines section as channels of a 2-D net) with the anti-aliasing add-on:
+    one dip field and one directional Laplacian per slice (Hale2D on a multi-channel BCHW tensor), regulariser value against the
+    numpy oracle at iteration 0."""
+    from deep_prior_interpolation_amd import utils as u
+    from deep_prior_interpolation_amd.main import Interpolator
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    g = golden("net_lines25d_tiny")
+    a = parse_arguments(["--imgdir", "x", "--datadim", "2.5d", "--imgchannel", "4", "--slice", "tx", "--filters", "4", "8", "16", "--skip", "4", "8",
+                         "--inputdepth", "8", "--upsample", "linear", "--gain", "1", "--epochs", "1", "--gpu", "0", "--aa_weight", "0.25"])
+    u.set_seed(0)
+    T = Interpolator(a, "/tmp")
+    T.load_data({"image": g["image"], "mask": g["mask"], "name": "0"})
+    T.build_model()
+    T.build_input()
+    T.build_regularizer()
+    assert tuple(T._aa_op.dips.shape) == (1, 4, 170, 100)
+    T.optimize(verbose=False)
+    out0 = np.asarray(T.out_best, dtype=np.float64).transpose(2, 0, 1)[None]            # (H,W,C) -> BCHW
+    reg_ref = np.abs(O.hale2d_np(out0, T._aa_op.dips.cpu().numpy().astype(np.float64))).mean()
+    assert abs(T.history.reg[0] - reg_ref) < 1e-4 * reg_ref + 1e-9
+    assert abs(T.history.loss[0] - (T.history.df[0] + 0.25 * T.history.reg[0])) < 1e-6 * abs(T.history.loss[0])
