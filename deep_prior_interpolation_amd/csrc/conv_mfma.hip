@@ -428,7 +428,6 @@ struct BwMArgs {
   // the in-volume samples when its rows enter the wave-private transpose buffer.  Lets a layer whose input is a raw conv output
   // with a pending BatchNorm + LeakyReLU chain keep the better-filled swapped orientation.
   const float* __restrict__ chain_a;
-  int debug;    // timing experiments only (DPI_BW_DEBUG): 1 skip the MFMA phase, 2 skip the dY row loads, 4 skip the X staging loads
 };
 
 // TC != 0: the launch covers a final group that holds only TC real channels (Cin = 4m + 1: TC = 1) and computes just their
@@ -503,7 +502,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
   if (t_begin < t_end) {
     tile_origin(t_begin, od0, oh0, ow0);
     tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
-    if (!(a.debug & 4)) stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
+    stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
   }
   for (int tile = t_begin; tile < t_end; ++tile) {
     TRW();
@@ -519,7 +518,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
     // fetches whole float4 pieces (lane -> channel l>>2, piece l&3 [+4]: 64 B contiguous per channel and instruction).
     auto load_raw = [&](f32x4 (&raw)[JP], int hr) {
       const int oh = coh0 + hr;
-      const bool row_ok = n0 + wch < a.Cout && cod < Do && oh < Ho && !(a.debug & 2);
+      const bool row_ok = n0 + wch < a.Cout && cod < Do && oh < Ho;
       const int base = wch * (int)Vo + (cod * Ho + oh) * Wo + cow0;       // host guarantees 16 * Vo * 4 < 2^31
 #pragma unroll
       for (int j = 0; j < JP; ++j) {
@@ -555,7 +554,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
     if (tile + 1 < t_end) {                                  // prefetch the next tile behind this tile's MFMAs
       tile_origin(tile + 1, od0, oh0, ow0);
       tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
-      if (!(a.debug & 4)) stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
+      stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
     }
     TRW();
     // Software pipeline (as in the forward kernel): the B operands of step (hr, s + 1) and the A row of hr + 1 are requested
@@ -582,10 +581,8 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
         if (s + 1 < KS) load_b(bn, hr, s + 1);
         else if (hr + 1 < NR) load_b(bn, hr + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(a.debug & 1)) {
 #pragma unroll
-          for (int t = 0; t < NTQ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(gc[s], bc[t], acc[t], 0, 0, 0);
-        }
+        for (int t = 0; t < NTQ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(gc[s], bc[t], acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) bc[t] = bn[t];
@@ -1037,8 +1034,7 @@ int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const f
                                  hipStream_t st) {
   const bool swap = dpi_conv_bwd_weight_mfma_swapped(d, chain);     // swapped: the chain moves to the A-operand rows (chain_a)
   const MfmaBwPlan p = mfma_bw_plan(d, swap);
-  BwMArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk, 0, 0, 0, p.nchunks, nullptr,
-            getenv("DPI_BW_DEBUG") ? atoi(getenv("DPI_BW_DEBUG")) : 0};
+  BwMArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk, 0, 0, 0, p.nchunks, nullptr};
   dim3 grid(p.nchunks, cdiv(d->Cin, 4), cdiv(d->Cout, 16));
   if (swap) {
     a.x = dy; a.chain = nullptr; a.dy = x; a.Cin = d->Cout; a.Cout = d->Cin; a.swap = 1; a.chain_a = chain;
