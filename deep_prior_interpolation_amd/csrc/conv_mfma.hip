@@ -424,10 +424,6 @@ struct BwMArgs {
   // rows — and the chunk's X halo rows — run back to back on ONE XCD and find them in its L2 instead of re-reading HBM
   // (measured before: 3.4 GB fetched per launch for 0.69 GB algorithmic on 25 -> 16).
   int ngroups, nchunks;
-  // swap = 1 only: per-channel chain of the tensor that plays the 16-row A operand (X in the swapped orientation), applied to
-  // the in-volume samples when its rows enter the wave-private transpose buffer.  Lets a layer whose input is a raw conv output
-  // with a pending BatchNorm + LeakyReLU chain keep the better-filled swapped orientation.
-  const float* __restrict__ chain_a;
 };
 
 // TC != 0: the launch covers a final group that holds only TC real channels (Cin = 4m + 1: TC = 1) and computes just their
@@ -526,18 +522,13 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
         raw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyb, (row_ok && cow0 + p4 < Wo) ? (base + p4) * 4 : -16, 0, 0));
       }
     };
-    const Chain cha = load_chain(a.chain_a, min(n0 + wch, a.Cout - 1));
-    auto put_row = [&](const f32x4 (&raw)[JP], int hr) {
-      const bool row_ok = n0 + wch < a.Cout && cod < Do && coh0 + hr < Ho;
+    auto put_row = [&](const f32x4 (&raw)[JP]) {
 #pragma unroll
       for (int j = 0; j < JP; ++j) {
         const int p4 = 4 * (wp + 4 * j);
         f32x4 v = raw[j];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bool in = row_ok && cow0 + p4 + e < Wo;                         // columns past the row end belong to the next row
-          v[e] = in ? (a.chain_a ? apply_chain(cha, v[e]) : v[e]) : 0.f;
-        }
+        for (int e = 0; e < 4; ++e) v[e] = cow0 + p4 + e < Wo ? v[e] : 0.f;   // columns past the row end belong to the next row
         *reinterpret_cast<f32x4*>(dyw + wch * DYRS + p4) = v;
       }
     };
@@ -565,9 +556,9 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
       for (int t = 0; t < NTQ; ++t) b[t] = lds[lbase + hr * S * G::RS + 4 * s_ * S + toff[t]];
     };
     float gc[KS], gn[KS], bc[NTQ], bn[NTQ];
-    put_row(raw[0], 0);
+    put_row(raw[0]);
     get_row(gc);
-    if (1 < NR) put_row(raw[1], 1);                             // LDS ops of a wave execute in order: safe after the reads above
+    if (1 < NR) put_row(raw[1]);                             // LDS ops of a wave execute in order: safe after the reads above
     load_b(bc, 0, 0);
 #pragma unroll
     for (int hr = 0; hr < NR; ++hr) {
@@ -576,7 +567,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
       for (int s = 0; s < KS; ++s) {
         if (s == KS / 2 && hr + 1 < NR) {                    // next row's A operands; then its successor may enter the row buffer
           get_row(gn);
-          if (hr + 2 < NR) put_row(raw[hr + 2], hr + 2);
+          if (hr + 2 < NR) put_row(raw[hr + 2]);
         }
         if (s + 1 < KS) load_b(bn, hr, s + 1);
         else if (hr + 1 < NR) load_b(bn, hr + 1, 0);
@@ -1028,16 +1019,16 @@ size_t dpi_conv_bwd_weight_mfma_ws_floats(const dpi_conv_desc* d) {
   const int n0 = mfma_bw_plan(d, false).nchunks, n1 = mfma_bw_swap_better(d) ? mfma_bw_plan(d, true).nchunks : 0;
   return (size_t)(n0 > n1 ? n0 : n1) * d->Cout * d->Cin * d->kd * 9;     // either orientation (the chain decides at run time)
 }
-bool dpi_conv_bwd_weight_mfma_swapped(const dpi_conv_desc* d, const float* chain) { (void)chain; return mfma_bw_swap_better(d); }
+bool dpi_conv_bwd_weight_mfma_swapped(const dpi_conv_desc* d, const float* chain) { return chain == nullptr && mfma_bw_swap_better(d); }
 
 int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws,
                                  hipStream_t st) {
-  const bool swap = dpi_conv_bwd_weight_mfma_swapped(d, chain);     // swapped: the chain moves to the A-operand rows (chain_a)
+  const bool swap = dpi_conv_bwd_weight_mfma_swapped(d, chain);     // the chain can only be applied to the staged tensor
   const MfmaBwPlan p = mfma_bw_plan(d, swap);
-  BwMArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk, 0, 0, 0, p.nchunks, nullptr};
+  BwMArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk, 0, 0, 0, p.nchunks};
   dim3 grid(p.nchunks, cdiv(d->Cin, 4), cdiv(d->Cout, 16));
   if (swap) {
-    a.x = dy; a.chain = nullptr; a.dy = x; a.Cin = d->Cout; a.Cout = d->Cin; a.swap = 1; a.chain_a = chain;
+    a.x = dy; a.chain = nullptr; a.dy = x; a.Cin = d->Cout; a.Cout = d->Cin; a.swap = 1;
     grid = dim3(p.nchunks, cdiv(d->Cout, 4), cdiv(d->Cin, 16));
   }
   // (chunk, group) grid -> 1-D XCD-aware order (see BwMArgs::ngroups)
