@@ -522,18 +522,13 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
         raw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyb, (row_ok && cow0 + p4 < Wo) ? (base + p4) * 4 : -16, 0, 0));
       }
     };
-    // (the row end only falls inside the tile for the last tile of a row: a wave-uniform test keeps the per-element masking —
-    //  8 VALU operations per float4 on the path that feeds the A operands — out of all the others)
-    const bool full_w = cow0 + 4 * KS <= Wo;
     auto put_row = [&](const f32x4 (&raw)[JP]) {
 #pragma unroll
       for (int j = 0; j < JP; ++j) {
         const int p4 = 4 * (wp + 4 * j);
         f32x4 v = raw[j];
-        if (!full_w) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = cow0 + p4 + e < Wo ? v[e] : 0.f;   // columns past the row end belong to the next row
-        }
+        for (int e = 0; e < 4; ++e) v[e] = cow0 + p4 + e < Wo ? v[e] : 0.f;   // columns past the row end belong to the next row
         *reinterpret_cast<f32x4*>(dyw + wch * DYRS + p4) = v;
       }
     };
