@@ -211,3 +211,45 @@ def test_default_net_fused_vs_leaf_at_128x64x64():
     errs = [rel(g1[k], g2[k]) for k in g1 if g1[k].ndim > 1]
     print("fused vs leaf at 128x64x64: weight-gradient error median %.2e max %.2e" % (np.median(errs), max(errs)))
     assert np.median(errs) < 1e-3 and max(errs) < 5e-2, (np.median(errs), max(errs))
+
+
+@pytest.mark.parametrize("cin,cout,k", [(64, 4, 3), (64, 25, 1), (25, 16, 3)])
+def test_conv_at_field_scale_patch(ops, cin, cout, k):
+    """BASELINE configs[4] geometry on one GPU: a 512x256x256 patch (33.5 M voxels; the 64-channel input alone is 2.1 G elements =
+    8.6 GB, past 32-bit ELEMENT indexing of a whole tensor).  Forward crops vs the fp64 oracle, backward-data crops, and the weight
+    gradient through the bilinear identity <W, dW> = <y, dy>."""
+    big = (512, 256, 256)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2 ** 30:
+        pytest.skip("needs ~60 GB of free HBM")
+    gen = torch.Generator(device=DEV).manual_seed(cin + cout)
+    x = torch.randn((1, cin) + big, device=DEV, generator=gen)
+    w = torch.randn((cout, cin, k, k, k), device=DEV, generator=gen) / np.sqrt(cin * k ** 3)
+    b = torch.randn(cout, device=DEV, generator=gen)
+    y = ops.conv(x, w, b, 1)
+    rng = np.random.RandomState(1)
+    D, H, W = big
+    boxes = [((0, 6), (0, 6), (0, 20)), ((D - 6, D), (H - 6, H), (W - 20, W)), ((D // 2 - 3, D // 2 + 3), (H - 6, H), (100, 120)),
+             ((D - 6, D), (3, 9), (W - 20, W))]
+    worst = 0.0
+    for box in boxes:
+        ref = _oracle_conv_on_crop(x, w, b, box, k, 1, big)
+        got = y[:, :, box[0][0]:box[0][1], box[1][0]:box[1][1], box[2][0]:box[2][1]]
+        worst = max(worst, rel(got, ref))
+    assert worst < 5e-6, worst
+    dy = torch.randn(y.shape, device=DEV, generator=gen)
+    d = ops.make_desc(x, w, 1)
+    dw = torch.empty_like(w)
+    ops.raw_conv_bwd_weight(d, x, None, dy, dw)
+    lhs = float(((y - b.view(1, -1, 1, 1, 1)).double() * dy.double()).sum())
+    assert abs(lhs - float((w.double() * dw.double()).sum())) < 2e-5 * abs(lhs) + 1e-1
+    del y
+    dx = torch.empty_like(x)
+    ops.raw_conv_bwd_data(d, dy, w, dx)
+    wt = w.flip(2, 3, 4).transpose(0, 1).contiguous() if k == 3 else w.transpose(0, 1).contiguous()
+    worst = 0.0
+    for box in boxes[:3]:
+        ref = _oracle_conv_on_crop(dy, wt, None, box, k, 1, big)
+        got = dx[:, :, box[0][0]:box[0][1], box[1][0]:box[1][1], box[2][0]:box[2][1]]
+        worst = max(worst, rel(got, ref))
+    assert worst < 5e-6, worst
