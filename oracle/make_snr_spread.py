@@ -2,6 +2,8 @@
 
     cd /tmp && python /root/repo/oracle/make_snr_spread.py --seeds 0 1 2 --threads 2      (one process per seed group)
     cd /tmp && python /root/repo/oracle/make_snr_spread.py --merge                        (-> tests/golden/snr_spread.npz)
+    cd /tmp && python /root/repo/oracle/make_snr_spread.py --plateau 96 64 64 --seeds 0 --epochs 600 --threads 8
+                                                                                  (-> tests/golden/plateau_96x64x64.npz)
 
 Drives the reference `Interpolator` (imported from /root/reference through oracle/ref_shim.py, exactly as
 proof_of_concept_3D.ipynb cell 15 does) on the (48,32,32) hyperbolic stand-in: default MulResUnet3D (5 923 614
@@ -34,11 +36,11 @@ ARGV = ["--imgdir", "/nonexistent", "--datadim", "3d", "--net", "multiunet", "--
         "--loss", "mae", "--lr", "1e-3", "--gain", "40", "--reg_noise_std", "0.03", "--noise_std", "0.1"]
 
 
-def stand_in():
+def stand_in(shape=SHAPE):
     """The volume/mask every seed shares (ours: deep_prior_interpolation_amd.utils.synthetic)."""
     from deep_prior_interpolation_amd.utils.synthetic import hyperbolic_volume, random_trace_mask
-    vol = hyperbolic_volume(SHAPE, seed=0).astype(np.float64)
-    mask = random_trace_mask(SHAPE, 0.66, seed=1).astype(np.float64)
+    vol = hyperbolic_volume(shape, seed=0).astype(np.float64)
+    mask = random_trace_mask(shape, 0.66, seed=1).astype(np.float64)
     return vol, mask
 
 
@@ -46,13 +48,13 @@ def snr_db(out, target):
     return 10.0 * np.log10(np.sum(target ** 2) / np.sum((target - out) ** 2))
 
 
-def run_seed(seed, epochs, threads):
+def run_seed(seed, epochs, threads, shape=SHAPE, save=True):
     torch.set_num_threads(threads)
     main = ref_shim.load_main()
     import utils as u  # reference module
     args = ref_shim.parse_args(ARGV + ["--epochs", str(epochs)])
     args.param_noise = False
-    vol, mask = stand_in()
+    vol, mask = stand_in(shape)
     image = (vol * args.gain)[..., None]
     u.set_seed(seed)
     T = main.Interpolator(args, tempfile.mkdtemp())
@@ -68,10 +70,33 @@ def run_seed(seed, epochs, threads):
          "loss": np.array(T.history.loss), "snr": np.array(T.history.snr), "pcorr": np.array(T.history.pcorr),
          "snr_out_best": np.float64(snr_db(out_best, image[..., 0])), "loss_min": np.float64(T.loss_min),
          "argmin": np.int64(int(np.argmin(T.history.loss))), "seconds": np.float64(dt)}
-    os.makedirs(PART, exist_ok=True)
-    np.savez_compressed(os.path.join(PART, "seed%03d.npz" % seed), **d)
+    if save:
+        os.makedirs(PART, exist_ok=True)
+        np.savez_compressed(os.path.join(PART, "seed%03d.npz" % seed), **d)
     print("seed %d: %.0f s, SNR(out_best) %.2f dB, min loss %.3e, final loss %.3e" %
           (seed, dt, d["snr_out_best"], d["loss_min"], d["loss"][-1]), flush=True)
+    return d
+
+
+def plateau(shape, seeds, epochs, threads):
+    """The all-zero plateau the optimisation starts on (MAE of a mostly-zero cube: the median is 0) and how long the reference
+    takes to leave it at a larger volume — the iteration count grows with the volume (SNR stays at 0 dB for ~150 iterations at
+    (48,32,32)), and it decides what a 3000-iteration run at 256x128x128 reaches.  Records the reference's loss / SNR history."""
+    import hashlib
+    parts = [run_seed(s, epochs, threads, shape=tuple(shape), save=False) for s in seeds]
+    vol, mask = stand_in(tuple(shape))
+    out = {"shape": np.array(shape), "argv": np.array(" ".join(ARGV)), "torch": np.array(torch.__version__),
+           "volume_sha1": np.array(hashlib.sha1(vol.astype(np.float32).tobytes()).hexdigest()),
+           "mask_sha1": np.array(hashlib.sha1(mask.astype(np.uint8).tobytes()).hexdigest())}
+    for k in ("seed", "threads", "epochs", "std", "seconds"):
+        out[k] = np.array([p[k] for p in parts])
+    for k in ("loss", "snr", "pcorr"):
+        out[k] = np.stack([p[k] for p in parts]).astype(np.float32)
+    name = "plateau_%s.npz" % "x".join(str(n) for n in shape)
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    for p in parts:
+        esc = int(np.argmax(p["snr"] > 1.0)) if (p["snr"] > 1.0).any() else -1
+        print("seed %d: first iteration with SNR > 1 dB: %d" % (p["seed"], esc))
 
 
 def merge():
@@ -96,8 +121,12 @@ if __name__ == "__main__":
     ap.add_argument("--threads", type=int, default=2)
     ap.add_argument("--epochs", type=int, default=1000)
     ap.add_argument("--merge", action="store_true")
+    ap.add_argument("--plateau", type=int, nargs=3, default=None, metavar=("NT", "NX", "NY"))
     a = ap.parse_args()
     ref_shim.install()
+    if a.plateau:
+        plateau(a.plateau, a.seeds or [0], a.epochs, a.threads)
+        sys.exit(0)
     for s in a.seeds:
         run_seed(s, a.epochs, a.threads)
     if a.merge:
