@@ -22,6 +22,9 @@ int dpi_conv_pw_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, cons
 size_t dpi_conv_bwd_weight_smallco_ws_floats(const dpi_conv_desc* d);
 int dpi_conv_bwd_weight_smallco_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws,
                                     hipStream_t st);
+bool dpi_conv_bf16_bww_usable(const dpi_conv_desc* d);
+size_t dpi_conv_bf16_bww_ws_floats(const dpi_conv_desc* d);
+int dpi_conv_bf16_bww_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws, hipStream_t st);
 static bool bw_use_smallco(const dpi_conv_desc* d) {
   return d->k == 3 && d->kd == 3 && d->stride == 1 && d->Cout <= 5 && (size_t)d->D * d->H * d->W >= 32768 &&
          (size_t)d->D * d->H * d->W < ((size_t)1 << 26);   // one 32-bit buffer offset spans the (<= 5) dY channels
@@ -288,6 +291,11 @@ BwPlan plan(const dpi_conv_desc* d) {
 
 extern "C" size_t dpi_conv_bwd_weight_ws_floats(const dpi_conv_desc* d) {
   if (!d || d->Cin <= 0 || d->Cout <= 0) return 0;
+  if (dpi_conv_bf16_bww_usable(d)) {          // the fp32 kernels stay the fallback for unaligned views: size for both
+    dpi_conv_desc f = *d;
+    f.precision = 0;
+    return std::max(dpi_conv_bf16_bww_ws_floats(d), dpi_conv_bwd_weight_ws_floats(&f));
+  }
   if (bw_use_mfma(d)) return dpi_conv_bwd_weight_mfma_ws_floats(d);
   // whether the swapped MFMA path runs depends on the chain given at launch: size for either
   const size_t sw = bw_use_mfma_swapped(d, nullptr) ? dpi_conv_bwd_weight_mfma_ws_floats(d) : 0;
@@ -303,6 +311,13 @@ extern "C" int dpi_conv_bwd_weight(const dpi_conv_desc* d, const float* x, const
   DPI_REQUIRE((d->k == 1 || d->k == 3) && (d->kd == d->k || d->kd == 1) && (d->stride == 1 || d->stride == 2),
               "conv_bwd_weight: unsupported k=%d kd=%d stride=%d", d->k, d->kd, d->stride);
   hipStream_t st = (hipStream_t)stream;
+  if (dpi_conv_bf16_bww_usable(d) && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0) {     // 16-byte staging loads
+    if (ws_floats < dpi_conv_bf16_bww_ws_floats(d)) {
+      dpi_set_error("conv_bwd_weight: workspace %zu < %zu floats", ws_floats, dpi_conv_bf16_bww_ws_floats(d));
+      return DPI_E_WORKSPACE;
+    }
+    return dpi_conv_bf16_bww_run(d, x, x_chain, dy, dw, ws, st);
+  }
   if (bw_use_mfma(d) || bw_use_mfma_swapped(d, x_chain)) {
     if (ws_floats < dpi_conv_bwd_weight_mfma_ws_floats(d)) {
       dpi_set_error("conv_bwd_weight: workspace %zu < %zu floats", ws_floats, dpi_conv_bwd_weight_mfma_ws_floats(d));

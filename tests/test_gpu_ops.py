@@ -571,3 +571,53 @@ def test_conv_bwd_weight_with_input_chain(ops, cin, cout, shape):
     dw2 = torch.empty_like(dw)
     ops.raw_conv_bwd_weight(d, tx, None, dy.to(DEV), dw2)                 # same thing with the chain materialised first
     assert rel(dw, dw2) < 2e-6
+
+
+# shapes with W a multiple of 4 (the kernel's 16-byte staging loads; others keep the fp32 kernels): ragged bands in h, ragged
+# 32-column runs, several depth chunks per band, channel counts below / at / above the 16-row blocks, one slice, one row
+BF16_BWW_CASES = [(25, 16, (12, 9, 40)), (64, 4, (8, 12, 36)), (4, 8, (9, 17, 32)), (8, 13, (8, 8, 32)), (25, 1, (8, 16, 32)),
+                  (67, 4, (6, 10, 36)), (35, 71, (8, 8, 8)), (17, 26, (6, 6, 4)), (9, 20, (16, 20, 72)), (16, 16, (3, 5, 20)),
+                  (5, 3, (1, 1, 4)), (51, 32, (32, 32, 64)), (25, 16, (64, 64, 64)), (8, 13, (62, 66, 68)), (137, 8, (20, 24, 64))]
+
+
+@pytest.mark.parametrize("cin,cout,shape", BF16_BWW_CASES)
+def test_conv_bwd_weight_bf16_mode_vs_oracle(ops, cin, cout, shape, monkeypatch):
+    """precision = 1, weight gradient (csrc/conv_bf16_bww.hip): X (after its chain) and dY rounded to bf16 (RNE) while staged,
+    exact products, fp32 accumulate.  (1) bf16-representable operands: the rounding is the identity and the kernel must match the
+    fp64 oracle like the fp32 kernels do (5e-6) — pins the band / ring / shifted-copy layout and the tap pairing.  (2) arbitrary
+    fp32 operands: equal to the oracle on the rounded operands (5e-6), and within the bf16 envelope of the exact gradient.
+    (3) with a pending chain on X: chain applied in fp32, then rounded."""
+    from deep_prior_interpolation_amd import _lib
+    monkeypatch.setattr(ops, "PRECISION", 1)
+    L = _lib.load()
+    L.dpi_set_bf16_debug(8)
+    try:
+        gen = torch.Generator().manual_seed(cin * 131 + cout)
+        x = torch.randn((1, cin) + shape, generator=gen)
+        dy = torch.randn((1, cout) + shape, generator=gen)
+        w = torch.zeros((cout, cin, 3, 3, 3))
+        xq, dyq = x.bfloat16().float(), dy.bfloat16().float()
+        wr = w.double().requires_grad_(True)
+        O.conv_nd(xq.double(), wr, None, 1).backward(dyq.double())
+        d = ops.make_desc(x.to(DEV), w.to(DEV), 1)
+        assert d.precision == 1
+        for xi, dyi in ((xq, dyq), (x, dy)):
+            dw = torch.full_like(w, float("nan"), device=DEV)
+            ops.raw_conv_bwd_weight(d, xi.to(DEV), None, dyi.to(DEV), dw)
+            assert rel(dw, wr.grad) < 5e-6
+        we = w.double().requires_grad_(True)
+        O.conv_nd(x.double(), we, None, 1).backward(dy.double())
+        assert rel(dw, we.grad) < 8e-3
+        # pending chain
+        chain = torch.stack([1.0 + 0.3 * torch.randn(cin, generator=gen), 0.2 * torch.randn(cin, generator=gen), torch.full((cin,), 0.2),
+                             1.0 + 0.3 * torch.randn(cin, generator=gen), 0.2 * torch.randn(cin, generator=gen)], dim=1).contiguous()
+        xg, cg = x.to(DEV), chain.to(DEV)
+        tx = torch.empty_like(xg)
+        ops.raw_chain_apply(xg, cg, cin, xg.numel() // cin, tx)
+        wc = w.double().requires_grad_(True)
+        O.conv_nd(tx.cpu().bfloat16().double(), wc, None, 1).backward(dyq.double())
+        dwc = torch.empty_like(w, device=DEV)
+        ops.raw_conv_bwd_weight(d, xg, cg, dyq.to(DEV), dwc)
+        assert rel(dwc, wc.grad) < 5e-6
+    finally:
+        L.dpi_set_bf16_debug(0)
