@@ -39,15 +39,20 @@ struct BwBArgs {
   int nth, ntw, ndc, dlen;     // bands (8 rows x 32 columns), depth chunks per band, slices per chunk
 };
 
-constexpr int TH = 8, TW = 32, XR = TH + 2;
+constexpr int TW = 32;
 constexpr int ROWW = 16 * 16;                 // words of one [16 channels][32 w bf16] row block (1 KB)
-constexpr int XSLOT = XR * ROWW;              // one X slice of the ring
-constexpr int DCOPY = TH * ROWW;              // one shifted copy of the dY slice
-constexpr int LDSW = 4 * XSLOT + 3 * DCOPY;   // 16384 words = 64 KB: two workgroups per CU
 
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {      // one v_cvt_pk_bf16_f32
   const f32x2 v = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// exact three-term split of two fp32 values, each term packed (lo | hi << 16): x = h + m + l, every difference exact in fp32
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = pack2(x0, x1);
+  const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = pack2(r0, r1);
+  const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+  l = pack2(s0, s1);
 }
 __device__ __forceinline__ float from_prev_lane(float v) {            // lane j <- lane j-1 (inside a row of 16 lanes)
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
@@ -56,10 +61,23 @@ __device__ __forceinline__ float from_next_lane(float v) {            // lane j 
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));
 }
 
-__global__ __launch_bounds__(256, 2) void conv_bf16_bwd_weight_kernel(BwBArgs a) {
+// NS = 1: bf16 mode, band of TH = 8 rows, 64 KB LDS (two workgroups per CU).
+// NS = 3: split mode — every operand as three bf16 terms (exact), the six partial products >= 2^-16 of the full one accumulated
+//         in fp32 (see conv_bf16_mfma.hip): fp32-class accuracy at 6 MFMAs per tap.  Three copies of everything in LDS, so the band
+//         is TH = 4 rows (108 KB, one workgroup per CU); the kernel becomes matrix-bound (162 MFMAs per wave and slice).
+template <int NS, int TH>
+__global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void conv_bf16_bwd_weight_kernel(BwBArgs a) {
+  constexpr int XR = TH + 2;                    // X rows of a slice (halo in h)
+  constexpr int XSLOT = XR * ROWW;              // one X slice of the ring
+  constexpr int DCOPY = TH * ROWW;              // one shifted copy of the dY slice
+  constexpr int XT = 4 * XSLOT, DT = 3 * DCOPY; // words per term
+  constexpr int LDSW = NS * (XT + DT);
+  constexpr int EX = XR / 2, EY = TH / 2;       // float4 pieces per thread and slice
+  constexpr int RW = TH / 4;                    // dY rows per wave
+  static_assert(LDSW >= 2 * 6912, "the wave reduction reuses the operand buffers");
   __shared__ __attribute__((aligned(16))) unsigned lds[LDSW];
-  unsigned* const xl = lds;
-  unsigned* const dl = lds + 4 * XSLOT;
+  unsigned* const xl = lds;                     // [term][slot][row][channel][16 words]
+  unsigned* const dl = lds + NS * XT;           // [term][copy][row][channel][16 words]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int ci0 = blockIdx.y * 16, co0 = blockIdx.z * 16;
   int b = blockIdx.x;
@@ -77,62 +95,74 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_bwd_weight_kernel(BwBArgs a)
   const float* __restrict__ xc = a.x + (size_t)(xch ? ci0 + ch : 0) * V;
   const float* __restrict__ yc = a.dy + (size_t)(ych ? co0 + ch : 0) * V;
   const Chain cx = load_chain(a.chain, xch ? ci0 + ch : 0);
-  int xoff[5], yoff[4];
+  int xoff[EX], yoff[EY];
 #pragma unroll
-  for (int e = 0; e < 5; ++e) {
+  for (int e = 0; e < EX; ++e) {
     const int gh = oh0 - 1 + 2 * e + rh;
     xoff[e] = (xch && gh >= 0 && gh < a.H && gw < a.W) ? gh * a.W + gw : -1;
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
+  for (int e = 0; e < EY; ++e) {
     const int gh = oh0 + 2 * e + rh;
     yoff[e] = (ych && gh < a.H && gw < a.W) ? gh * a.W + gw : -1;
   }
   // the dY columns next to the run (w = u0 - 1, u0 + 32) feed the shifted copies: fetched by the first / last piece of a row
   const int hdelta = q == 0 ? (u0 > 0 ? -1 : 0) : q == 7 ? (u0 + TW < a.W ? 4 : 0) : 0;
 
-  float4 xr[5], yr[4];
-  float hr[4];
+  float4 xr[EX], yr[EY];
+  float hr[EY];
   bool x_live = false;
   auto load_x = [&](int slice) {
     x_live = slice >= 0 && slice < a.D;
     const float* __restrict__ p = xc + (size_t)(x_live ? slice : 0) * HW;
 #pragma unroll
-    for (int e = 0; e < 5; ++e)
+    for (int e = 0; e < EX; ++e)
       xr[e] = (x_live && xoff[e] >= 0) ? *reinterpret_cast<const float4*>(p + xoff[e]) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto load_dy = [&](int slice) {
     const float* __restrict__ p = yc + (size_t)slice * HW;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < EY; ++e) {
       yr[e] = yoff[e] >= 0 ? *reinterpret_cast<const float4*>(p + yoff[e]) : make_float4(0.f, 0.f, 0.f, 0.f);
       hr[e] = (hdelta != 0 && yoff[e] >= 0) ? p[yoff[e] + hdelta] : 0.f;
+    }
+  };
+  // two packed pairs -> the NS term planes (stride `ts` words) at `o`
+  auto put = [&](unsigned* __restrict__ o, int ts, float p0, float p1, float p2, float p3) {
+    if constexpr (NS == 1) {
+      *reinterpret_cast<u32x2*>(o) = (u32x2){pack2(p0, p1), pack2(p2, p3)};
+    } else {
+      unsigned h0, m0, l0, h1, m1, l1;
+      split3_pair(p0, p1, h0, m0, l0);
+      split3_pair(p2, p3, h1, m1, l1);
+      *reinterpret_cast<u32x2*>(o) = (u32x2){h0, h1};
+      *reinterpret_cast<u32x2*>(o + ts) = (u32x2){m0, m1};
+      *reinterpret_cast<u32x2*>(o + 2 * ts) = (u32x2){l0, l1};
     }
   };
   auto store_x = [&](int slot) {
     unsigned* __restrict__ dst = xl + slot * XSLOT + (rh * 16 + ch) * 16 + 2 * q;
 #pragma unroll
-    for (int e = 0; e < 5; ++e) {
+    for (int e = 0; e < EX; ++e) {
       float4 v = xr[e];
       if (a.chain && x_live && xoff[e] >= 0) {                 // zero padding stays zero
         v.x = apply_chain(cx, v.x); v.y = apply_chain(cx, v.y); v.z = apply_chain(cx, v.z); v.w = apply_chain(cx, v.w);
       }
-      *reinterpret_cast<u32x2*>(dst + 2 * e * ROWW) = (u32x2){pack2(v.x, v.y), pack2(v.z, v.w)};
+      put(dst + 2 * e * ROWW, XT, v.x, v.y, v.z, v.w);
     }
   };
   auto store_dy = [&]() {
     unsigned* __restrict__ dst = dl + (rh * 16 + ch) * 16 + 2 * q;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < EY; ++e) {
       const float4 v = yr[e];
       float left = from_prev_lane(v.w), right = from_next_lane(v.x);
       left = q == 0 ? hr[e] : left;
       right = q == 7 ? hr[e] : right;
-      const unsigned mid = pack2(v.y, v.z);
       unsigned* __restrict__ o = dst + 2 * e * ROWW;
-      *reinterpret_cast<u32x2*>(o) = (u32x2){mid, pack2(v.w, right)};                       // kw = 0: copy[u] = dY[u + 1]
-      *reinterpret_cast<u32x2*>(o + DCOPY) = (u32x2){pack2(v.x, v.y), pack2(v.z, v.w)};     // kw = 1
-      *reinterpret_cast<u32x2*>(o + 2 * DCOPY) = (u32x2){pack2(left, v.x), mid};            // kw = 2: copy[u] = dY[u - 1]
+      put(o, DT, v.y, v.z, v.w, right);                        // kw = 0: copy[u] = dY[u + 1]
+      put(o + DCOPY, DT, v.x, v.y, v.z, v.w);                  // kw = 1
+      put(o + 2 * DCOPY, DT, left, v.x, v.y, v.z);             // kw = 2: copy[u] = dY[u - 1]
     }
   };
 
@@ -147,33 +177,46 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_bwd_weight_kernel(BwBArgs a)
   load_dy(d0);
 
   const int fo = (lane & 15) * 16 + (lane >> 4) * 4;           // this lane's 16 bytes inside a row block
+  auto frag = [&](const unsigned* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p)); };
   for (int d = d0; d < d1; ++d) {
     __syncthreads();                                           // the previous slice's dY copies have been read
     store_x((d + 2) & 3);                                      // slice d + 1
     store_dy();
     __syncthreads();
     if (d + 1 < d1) { load_x(d + 2); load_dy(d + 1); }         // in flight behind this slice's MFMAs
-    bf16x8 A[3][2];
+    bf16x8 A[NS][3][RW];
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int n = 0; n < NS; ++n)
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
-        A[s][r] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(dl + s * DCOPY + (2 * wid + r) * ROWW + fo));
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) A[n][s][r] = frag(dl + n * DT + s * DCOPY + (RW * wid + r) * ROWW + fo);
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd) {
-      const unsigned* __restrict__ xs = xl + ((d + kd) & 3) * XSLOT + 2 * wid * ROWW + fo;     // slice d - 1 + kd
+      const unsigned* __restrict__ xs = xl + ((d + kd) & 3) * XSLOT + RW * wid * ROWW + fo;     // slice d - 1 + kd
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {                            // X row 2 wid + t of the slice pairs with dY row r at kh = t - r
-        const bf16x8 B = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xs + t * ROWW));
-        if (t <= 2) {
+      for (int t = 0; t < RW + 2; ++t) {                       // X row RW wid + t of the slice pairs with dY row r at kh = t - r
+        bf16x8 B[NS];
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw)
-            acc[(kd * 3 + t) * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kw][0], B, acc[(kd * 3 + t) * 3 + kw], 0, 0, 0);
-        }
-        if (t >= 1) {
+        for (int n = 0; n < NS; ++n) B[n] = frag(xs + n * XT + t * ROWW);
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw)
-            acc[(kd * 3 + t - 1) * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kw][1], B, acc[(kd * 3 + t - 1) * 3 + kw], 0, 0, 0);
+        for (int r = 0; r < RW; ++r) {
+          const int kh = t - r;
+          if (kh < 0 || kh > 2) continue;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            f32x4& c = acc[(kd * 3 + kh) * 3 + kw];
+            if constexpr (NS == 1) {
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][kw][r], B[0], c, 0, 0, 0);
+            } else {                                           // smallest terms first: l*h, h*l, m*m (2^-16), m*h, h*m (2^-8), h*h
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2][kw][r], B[0], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][kw][r], B[2], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][kw][r], B[1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][kw][r], B[0], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][kw][r], B[1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][kw][r], B[0], c, 0, 0, 0);
+            }
+          }
         }
       }
     }
@@ -222,12 +265,16 @@ struct BwBPlan { int nth, ntw, ndc, dlen, nchunks; };
 
 }  // namespace
 
+bool dpi_bf16_force_all();
+
 static BwBPlan bf16_bww_plan(const dpi_conv_desc* d) {
   BwBPlan p{};
+  const int TH = d->precision == 2 ? 4 : 8;
   p.nth = cdiv(d->H, TH); p.ntw = cdiv(d->W, TW);
   const int bands = p.nth * p.ntw, blocks = cdiv(d->Cin, 16) * cdiv(d->Cout, 16);
   const size_t per = (size_t)d->Cout * d->Cin * 27;
-  size_t want = cdivz(1536, (size_t)bands * blocks);           // depth chunks per band: ~1536 workgroups (3 rounds of 2 per CU)
+  // depth chunks per band: ~1536 workgroups (3 rounds of 2 per CU); split mode: ~1024 (4 rounds of 1 per CU)
+  size_t want = cdivz(d->precision == 2 ? 1024 : 1536, (size_t)bands * blocks);
   const size_t mem = (((size_t)32 << 20) / per) / bands;       // the workspace stays <= 128 MB
   if (want > mem) want = mem;
   if (want > (size_t)cdiv(d->D, 4)) want = cdiv(d->D, 4);      // >= 4 slices per chunk: two extra X slices are staged per chunk
@@ -243,7 +290,11 @@ static BwBPlan bf16_bww_plan(const dpi_conv_desc* d) {
 // 25->16 @256x128x128 1.20 -> 0.29 ms, 64->4 0.62 -> 0.34, 51->32 @128x64x64 0.48 -> 0.11, 105->64 @64x32x32 0.28 -> 0.07,
 // 212->128 @32x16x16 0.26 -> 0.065, 142->213 @16x8x8 0.090 -> 0.036: faster everywhere, so no size threshold.
 bool dpi_conv_bf16_bww_usable(const dpi_conv_desc* d) {
-  if (d->precision != 1 || d->k != 3 || d->kd != 3 || d->stride != 1 || (d->W & 3)) return false;
+  if (d->precision < 1 || d->k != 3 || d->kd != 3 || d->stride != 1 || (d->W & 3)) return false;
+  // split mode is matrix-bound (6 MFMAs per tap on 16 x 16 channel blocks): it beats the fp32 kernels where both channel counts
+  // fill a block (25->16 1.20 -> 0.77 ms, 51->32 0.48 -> 0.34, 105->64 0.28 -> 0.19, 212->128 0.26 -> 0.19) and loses on the
+  // few-channel layers (64->4 0.62 -> 1.29, 8->13 0.33 -> 0.37, 137->8 0.33 -> 0.41), which keep the fp32 kernels
+  if (d->precision == 2 && !dpi_bf16_force_all() && (d->Cin < 16 || d->Cout < 16)) return false;
   return (size_t)d->D * d->H * d->W < ((size_t)1 << 29);
 }
 
@@ -253,7 +304,8 @@ int dpi_conv_bf16_bww_run(const dpi_conv_desc* d, const float* x, const float* c
   const BwBPlan p = bf16_bww_plan(d);
   BwBArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.nth, p.ntw, p.ndc, p.dlen};
   dim3 grid(p.nchunks, cdiv(d->Cin, 16), cdiv(d->Cout, 16));
-  conv_bf16_bwd_weight_kernel<<<grid, 256, 0, st>>>(a);
+  if (d->precision == 2) conv_bf16_bwd_weight_kernel<3, 4><<<grid, 256, 0, st>>>(a);
+  else conv_bf16_bwd_weight_kernel<1, 8><<<grid, 256, 0, st>>>(a);
   if (int e = dpi_check_launch("conv_bf16_bwd_weight")) return e;
   dpi_reduce_chunks(ws, dw, (size_t)d->Cout * d->Cin * 27, p.nchunks, st);
   return dpi_check_launch("reduce_chunks");

@@ -324,6 +324,7 @@ static int bf16_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth
 
 static int g_bf16_debug = 0;
 static int g_bf16_all = 0;      // 1: every 3x3(x3) stride-1 convolution (tests); 0: only where the kernel beats the fp32 one
+bool dpi_bf16_force_all() { return g_bf16_all != 0; }
 extern "C" void dpi_set_bf16_debug(int flags) { g_bf16_debug = flags & 7; g_bf16_all = (flags >> 3) & 1; g_split_nh = (flags & 16) ? 1 : 2; g_bf16_nh = (flags & 32) ? 1 : 2; }
 
 // Where the mode applies (measured in the iteration, profiles/r02_bf16_kernel_stats_layers.txt): the big-tile variant — full

@@ -621,3 +621,36 @@ def test_conv_bwd_weight_bf16_mode_vs_oracle(ops, cin, cout, shape, monkeypatch)
         assert rel(dwc, wc.grad) < 5e-6
     finally:
         L.dpi_set_bf16_debug(0)
+
+
+@pytest.mark.parametrize("cin,cout,shape", BF16_BWW_CASES)
+def test_conv_bwd_weight_split_mode_has_fp32_accuracy(ops, cin, cout, shape, monkeypatch):
+    """precision = 2, weight gradient: X (after its chain) and dY each split exactly into three bf16 terms, six partial products
+    in fp32.  ARBITRARY fp32 operands with 4 decades of channel scale, the fp32 kernels' own tolerance against the fp64 oracle
+    (5e-6), and an error of the same class as the fp32 kernel's on the same inputs (within 4x)."""
+    from deep_prior_interpolation_amd import _lib
+    gen = torch.Generator().manual_seed(cin * 17 + cout)
+    x = torch.randn((1, cin) + shape, generator=gen) * torch.logspace(-2, 2, cin).view(1, -1, 1, 1, 1)
+    dy = torch.randn((1, cout) + shape, generator=gen) * torch.logspace(-1, 1, cout).view(1, -1, 1, 1, 1)
+    w = torch.zeros((cout, cin, 3, 3, 3))
+    chain = torch.stack([1.0 + 0.3 * torch.randn(cin, generator=gen), 0.2 * torch.randn(cin, generator=gen), torch.full((cin,), 0.2),
+                         1.0 + 0.3 * torch.randn(cin, generator=gen), 0.2 * torch.randn(cin, generator=gen)], dim=1).contiguous()
+    xg, cg, dyg = x.to(DEV), chain.to(DEV), dy.to(DEV)
+    tx = torch.empty_like(xg)
+    ops.raw_chain_apply(xg, cg, cin, xg.numel() // cin, tx)
+    wr = w.double().requires_grad_(True)
+    O.conv_nd(tx.cpu().double(), wr, None, 1).backward(dy.double())
+    errs = {}
+    for prec in (2, 0):
+        monkeypatch.setattr(ops, "PRECISION", prec)
+        _lib.load().dpi_set_bf16_debug(8 if prec else 0)      # every layer through the split kernel (by default only where it pays)
+        try:
+            d = ops.make_desc(xg, w.to(DEV), 1)
+            assert d.precision == prec
+            dw = torch.full_like(w, float("nan"), device=DEV)
+            ops.raw_conv_bwd_weight(d, xg, cg, dyg, dw)
+        finally:
+            _lib.load().dpi_set_bf16_debug(0)
+        errs[prec] = rel(dw, wr.grad)
+    assert errs[2] < 5e-6, errs
+    assert errs[2] < 4 * errs[0] + 1e-7, errs
