@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--cpu-patch", type=int, nargs=3, default=[64, 64, 64])
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--mode", default="auto", choices=["auto", "eager", "graph"])
-    ap.add_argument("--patches", type=int, default=8, help="c3: patches per rank taken from the queue")
+    ap.add_argument("--patches", type=int, default=12, help="c3: patches per rank taken from the queue (a multiple of --concurrent avoids a part-filled last round)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "split"],
                     help="bf16: BASELINE configs[4] mixed precision (bf16 MFMA operands in the 3x3x3 convs, fp32 accumulate / storage / Adam); "
                          "a SECOND bench line, the headline stays fp32")
@@ -334,7 +334,7 @@ def run_c3(a, rank, world, device):
     loop_rate = len(mine) * a.steps / max(timings.get("loop_s", dt), 1e-9)
     return {"metric": "Adam iters/sec on 3D MultiRes-UNet per GPU", "value": round(rate, 3), "unit": "it/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "split": "f32 (3 x bf16 split)"}[a.precision], "data": "synthetic",
             "config": {"workload": "configs[2]: 256^3 synthetic volume, 50 %% missing traces, %dx%dx%d patches stride %d (%d windows); queue of %d "
                                    "patches (%d per rank) pulled from the shared counter, %d concurrent hipGraph patches per GPU, %d Adam iterations "
                                    "each; timed end to end incl. per-patch set-up, dpi_overlap_add, the all-reduce and normalisation; a step = one "

@@ -74,6 +74,8 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void conv_bf16_bwd_weight_ker
   constexpr int LDSW = NS * (XT + DT);
   constexpr int EX = XR / 2, EY = TH / 2;       // float4 pieces per thread and slice
   constexpr int RW = TH / 4;                    // dY rows per wave
+  constexpr int PF = 1;                         // slices of prefetch held in registers (2 measured no faster in split mode: its
+                                                // single workgroup per CU serialises staging, LDS reads and MFMAs, not HBM latency)
   static_assert(LDSW >= 2 * 6912, "the wave reduction reuses the operand buffers");
   __shared__ __attribute__((aligned(16))) unsigned lds[LDSW];
   unsigned* const xl = lds;                     // [term][slot][row][channel][16 words]
@@ -109,22 +111,34 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void conv_bf16_bwd_weight_ker
   // the dY columns next to the run (w = u0 - 1, u0 + 32) feed the shifted copies: fetched by the first / last piece of a row
   const int hdelta = q == 0 ? (u0 > 0 ? -1 : 0) : q == 7 ? (u0 + TW < a.W ? 4 : 0) : 0;
 
-  float4 xr[EX], yr[EY];
-  float hr[EY];
-  bool x_live = false;
-  auto load_x = [&](int slice) {
-    x_live = slice >= 0 && slice < a.D;
-    const float* __restrict__ p = xc + (size_t)(x_live ? slice : 0) * HW;
+  // PF register stages of prefetch: stage 0 is stored next, stage PF-1 was loaded last
+  float4 xr[PF][EX], yr[PF][EY];
+  float hr[PF][EY];
+  bool x_live[PF];
+  auto load_x = [&](int st, int slice) {
+    x_live[st] = slice >= 0 && slice < a.D;
+    const float* __restrict__ p = xc + (size_t)(x_live[st] ? slice : 0) * HW;
 #pragma unroll
     for (int e = 0; e < EX; ++e)
-      xr[e] = (x_live && xoff[e] >= 0) ? *reinterpret_cast<const float4*>(p + xoff[e]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xr[st][e] = (x_live[st] && xoff[e] >= 0) ? *reinterpret_cast<const float4*>(p + xoff[e]) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
-  auto load_dy = [&](int slice) {
-    const float* __restrict__ p = yc + (size_t)slice * HW;
+  auto load_dy = [&](int st, int slice) {
+    const bool live = slice < d1;
+    const float* __restrict__ p = yc + (size_t)(live ? slice : 0) * HW;
 #pragma unroll
     for (int e = 0; e < EY; ++e) {
-      yr[e] = yoff[e] >= 0 ? *reinterpret_cast<const float4*>(p + yoff[e]) : make_float4(0.f, 0.f, 0.f, 0.f);
-      hr[e] = (hdelta != 0 && yoff[e] >= 0) ? p[yoff[e] + hdelta] : 0.f;
+      yr[st][e] = (live && yoff[e] >= 0) ? *reinterpret_cast<const float4*>(p + yoff[e]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      hr[st][e] = (live && hdelta != 0 && yoff[e] >= 0) ? p[yoff[e] + hdelta] : 0.f;
+    }
+  };
+  auto advance = [&]() {
+#pragma unroll
+    for (int st = 0; st + 1 < PF; ++st) {
+      x_live[st] = x_live[st + 1];
+#pragma unroll
+      for (int e = 0; e < EX; ++e) xr[st][e] = xr[st + 1][e];
+#pragma unroll
+      for (int e = 0; e < EY; ++e) { yr[st][e] = yr[st + 1][e]; hr[st][e] = hr[st + 1][e]; }
     }
   };
   // two packed pairs -> the NS term planes (stride `ts` words) at `o`
@@ -144,8 +158,8 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void conv_bf16_bwd_weight_ker
     unsigned* __restrict__ dst = xl + slot * XSLOT + (rh * 16 + ch) * 16 + 2 * q;
 #pragma unroll
     for (int e = 0; e < EX; ++e) {
-      float4 v = xr[e];
-      if (a.chain && x_live && xoff[e] >= 0) {                 // zero padding stays zero
+      float4 v = xr[0][e];
+      if (a.chain && x_live[0] && xoff[e] >= 0) {                 // zero padding stays zero
         v.x = apply_chain(cx, v.x); v.y = apply_chain(cx, v.y); v.z = apply_chain(cx, v.z); v.w = apply_chain(cx, v.w);
       }
       put(dst + 2 * e * ROWW, XT, v.x, v.y, v.z, v.w);
@@ -155,10 +169,10 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void conv_bf16_bwd_weight_ker
     unsigned* __restrict__ dst = dl + (rh * 16 + ch) * 16 + 2 * q;
 #pragma unroll
     for (int e = 0; e < EY; ++e) {
-      const float4 v = yr[e];
+      const float4 v = yr[0][e];
       float left = from_prev_lane(v.w), right = from_next_lane(v.x);
-      left = q == 0 ? hr[e] : left;
-      right = q == 7 ? hr[e] : right;
+      left = q == 0 ? hr[0][e] : left;
+      right = q == 7 ? hr[0][e] : right;
       unsigned* __restrict__ o = dst + 2 * e * ROWW;
       put(o, DT, v.y, v.z, v.w, right);                        // kw = 0: copy[u] = dY[u + 1]
       put(o + DCOPY, DT, v.x, v.y, v.z, v.w);                  // kw = 1
@@ -171,10 +185,10 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void conv_bf16_bwd_weight_ker
   for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ring slot of slice s is (s + 1) & 3
-  load_x(d0 - 1); store_x(d0 & 3);
-  load_x(d0); store_x((d0 + 1) & 3);
-  load_x(d0 + 1);
-  load_dy(d0);
+  load_x(0, d0 - 1); store_x(d0 & 3);
+  load_x(0, d0); store_x((d0 + 1) & 3);
+#pragma unroll
+  for (int st = 0; st < PF; ++st) { load_x(st, d0 + 1 + st); load_dy(st, d0 + st); }
 
   const int fo = (lane & 15) * 16 + (lane >> 4) * 4;           // this lane's 16 bytes inside a row block
   auto frag = [&](const unsigned* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p)); };
@@ -183,7 +197,8 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void conv_bf16_bwd_weight_ker
     store_x((d + 2) & 3);                                      // slice d + 1
     store_dy();
     __syncthreads();
-    if (d + 1 < d1) { load_x(d + 2); load_dy(d + 1); }         // in flight behind this slice's MFMAs
+    advance();
+    if (d + PF < d1) { load_x(PF - 1, d + PF + 1); load_dy(PF - 1, d + PF); }   // in flight behind the MFMAs of PF slices
     bf16x8 A[NS][3][RW];
 #pragma unroll
     for (int n = 0; n < NS; ++n)
@@ -203,19 +218,18 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void conv_bf16_bwd_weight_ker
         for (int r = 0; r < RW; ++r) {
           const int kh = t - r;
           if (kh < 0 || kh > 2) continue;
+          f32x4* const c = &acc[(kd * 3 + kh) * 3];
+          if constexpr (NS == 1) {
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            f32x4& c = acc[(kd * 3 + kh) * 3 + kw];
-            if constexpr (NS == 1) {
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][kw][r], B[0], c, 0, 0, 0);
-            } else {                                           // smallest terms first: l*h, h*l, m*m (2^-16), m*h, h*m (2^-8), h*h
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2][kw][r], B[0], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][kw][r], B[2], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][kw][r], B[1], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][kw][r], B[0], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][kw][r], B[1], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][kw][r], B[0], c, 0, 0, 0);
-            }
+            for (int kw = 0; kw < 3; ++kw) c[kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][kw][r], B[0], c[kw], 0, 0, 0);
+          } else {
+            // smallest terms first: l*h, h*l, m*m (2^-16), m*h, h*m (2^-8), h*h; the three kw accumulators alternate so that
+            // consecutive MFMAs never wait for each other's result
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+              for (int kw = 0; kw < 3; ++kw) c[kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA[p]][kw][r], B[TB[p]], c[kw], 0, 0, 0);
           }
         }
       }
