@@ -64,7 +64,11 @@ __device__ __forceinline__ float from_next_lane(float v) {            // lane j 
 // NS = 1: bf16 mode, band of TH = 8 rows, 64 KB LDS (two workgroups per CU).
 // NS = 3: split mode — every operand as three bf16 terms (exact), the six partial products >= 2^-16 of the full one accumulated
 //         in fp32 (see conv_bf16_mfma.hip): fp32-class accuracy at 6 MFMAs per tap.  Three copies of everything in LDS, so the band
-//         is TH = 4 rows (108 KB, one workgroup per CU); the kernel becomes matrix-bound (162 MFMAs per wave and slice).
+//         is TH = 4 rows (108 KB, one workgroup per CU) with 162 MFMAs per wave and slice.  Measured 25->16: 0.78-0.80 ms against a
+//         0.3 ms matrix floor and a 0.23 ms HBM floor: the two phases of a slice (loads in flight / MFMAs) are of equal length and
+//         do not overlap well.  Tried without gain: a second register stage of prefetch; an 8-wave workgroup whose wave pairs
+//         share a dY row and split the six products (all waves still stage and multiply in the same phases — it needs
+//         producer / consumer waves, not a symmetric split).
 template <int NS, int TH>
 __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void conv_bf16_bwd_weight_kernel(BwBArgs a) {
   constexpr int XR = TH + 2;                    // X rows of a slice (halo in h)
