@@ -254,3 +254,38 @@ def test_antialiasing_addon_on_25d_slabs(golden):
     reg_ref = np.abs(O.hale2d_np(out0, T._aa_op.dips.cpu().numpy().astype(np.float64))).mean()
     assert abs(T.history.reg[0] - reg_ref) < 1e-4 * reg_ref + 1e-9
     assert abs(T.history.loss[0] - (T.history.df[0] + 0.25 * T.history.reg[0])) < 1e-6 * abs(T.history.loss[0])
+
+
+@pytest.mark.parametrize("shape", [(20, 18, 36), (17, 19, 22), (32, 32, 64)])
+def test_precision_modes_through_the_loop_at_awkward_shapes(shape):
+    """--precision fp32 / bf16 / split through Interpolator.optimize on shapes that mix the kernel families inside one net: rows
+    that are / are not whole float4 (the bf16 backward-weight kernel needs them, the fp32 kernels take the rest), odd extents
+    (ragged tiles at every level, crops after up-sampling).  Same seed, same noise stream: iteration 0 is the same forward pass,
+    so its loss must agree to the mode's operand rounding (bf16: 2^-9 per operand -> 5e-3; split: fp32 class -> 2e-5), and ten
+    iterations must stay finite and on the same loss level."""
+    from deep_prior_interpolation_amd import ops, utils as u
+    from deep_prior_interpolation_amd.main import Interpolator
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    vol = u.hyperbolic_volume(shape, seed=3)
+    mask = u.random_trace_mask(shape, 0.5, seed=4)
+    losses = {}
+    try:
+        for prec in ("fp32", "bf16", "split"):
+            args = parse_arguments(["--imgdir", "synthetic", "--datadim", "3d", "--net", "multiunet", "--inputdepth", "16", "--upsample", "linear",
+                                    "--loss", "mae", "--lr", "1e-3", "--gain", "40", "--epochs", "10", "--gpu", "0", "--precision", prec])
+            u.set_seed(7)
+            T = Interpolator(args, "/tmp", seed=7)
+            T.load_data({"image": (vol.astype(np.float64) * 40)[..., None], "mask": mask.astype(np.float64)[..., None], "name": "0"})
+            T.build_model()
+            T.build_input()
+            T.optimize(verbose=False)
+            losses[prec] = np.array(T.history.loss)
+            assert np.isfinite(losses[prec]).all() and np.isfinite(np.asarray(T.out_best)).all(), prec
+    finally:
+        ops.set_precision("fp32")
+    ref = losses["fp32"]
+    print(shape, {k: [round(float(x), 5) for x in v[:3]] for k, v in losses.items()})
+    assert abs(losses["bf16"][0] - ref[0]) <= 5e-3 * ref[0]
+    assert abs(losses["split"][0] - ref[0]) <= 2e-5 * ref[0]
+    for prec in ("bf16", "split"):
+        assert abs(losses[prec][-1] - ref[-1]) <= 0.1 * ref[-1], prec

@@ -1,3 +1,5 @@
+# HBM counters (FETCH_SIZE, WRITE_SIZE: separate passes) of an iteration with --precision bf16, per launch grid for the bf16 kernels and summed over
+# the iteration.  Run on the GPU box: bash tools/pmc_bf16.sh   ->  gpurun_out/r02_bf16v2_pmc_*.txt, r02_bf16v2_hbm_iteration_*.txt
 set -u
 repo=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
