@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--patch", type=int, nargs=3, default=None)
     ap.add_argument("--upsample", default="linear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-modes", action="store_true", help="c2: skip the short bf16 / split passes reported under other_modes")
     ap.add_argument("--cpu-patch", type=int, nargs=3, default=[64, 64, 64])
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--mode", default="auto", choices=["auto", "eager", "graph"])
@@ -267,6 +268,23 @@ def run_c2(a, rank, world, device):
                     "achieved_tflops": round(ach, 1),
                     "note": "fp32 tensors in HBM (the mode rounds operands on the way into LDS); traffic not measured for this mode",
                     "whole_iteration": whole}
+    # the other arithmetic modes on the same patch, right after the timed region (information only: `value` above is the mode asked for)
+    other = None
+    if a.precision == "fp32" and world == 1 and mode == "eager" and not a.no_other_modes:
+        other = {}
+        for prec, label in (("bf16", "bf16"), ("split", "f32 (3 x bf16 split)")):
+            ops.set_precision(prec)
+            for _ in range(2):
+                eager_step()
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                eager_step()
+            torch.cuda.synchronize(device)
+            dtp = time.perf_counter() - t1
+            other[prec] = {"dtype": label, "ms_per_step": round(dtp / a.steps * 1e3, 3), "value": round(a.steps / dtp, 4), "unit": "it/s",
+                           "steps": a.steps, "note": "python bench.py --precision %s reports this mode as its own line" % prec}
+        ops.set_precision("fp32")
     cpu = None
     if not (a.no_cpu_baseline or world > 1):
         cpu = cpu_baseline(a.patch, a.cpu_patch, a.upsample, a.cpu_iters, gpu_small_patch_rate(a.cpu_patch, a.upsample, device))
@@ -279,7 +297,7 @@ def run_c2(a, rank, world, device):
                                             "accumulated in fp32: fp32-class accuracy on the bf16 matrix cores) — "}[a.precision] + "configs[1]: MulResUnet3D defaults (5923614 params), patch %dx%dx%d, inputdepth 64, %s, MAE, "
                                    "one independent patch per GPU, loop mode %s" % (tuple(a.patch) + (args.upsample, mode)),
                        "last_loss": T.history.loss[-1], "last_snr_db": T.history.snr[-1]},
-            "roofline": roof, "cpu_baseline": cpu}
+            "roofline": roof, "cpu_baseline": cpu, "other_modes": other}
 
 
 def run_c3(a, rank, world, device):

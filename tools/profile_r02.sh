@@ -10,7 +10,7 @@ repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-BENCH="$repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_EXTRA:-}"
+BENCH="$repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-modes ${BENCH_EXTRA:-}"
 
 trace() {   # name, then env assignments are taken from the caller's environment
   local name=$1
