@@ -6,15 +6,15 @@ beyond ~10 iterations (tests/test_gpu_nets.py covers those).  What can be compar
 
   tests/golden/snr_spread.npz   recorded by oracle/make_snr_spread.py from the reference's own Interpolator (imported from
                                 /root/reference): (48,32,32) hyperbolic stand-in, 66 % missing traces, default MulResUnet3D,
-                                gain 40, MAE, trilinear, param_noise=False, 1000 Adam iterations, seeds 0..23.
+                                gain 40, MAE, trilinear, param_noise=False, 1000 Adam iterations, seeds 0..47.
   here                          the HIP path on the same volume / mask / hyper-parameters, same seeds (bit-identical initial
                                 weights, tests/test_host.py), its own Philox noise stream, 1000 iterations per seed.
 
 Reported (pytest -s): the difference of the mean SNR(out_best) with 2 standard errors of that difference, the
 same for the minimum loss.  Asserted: both differences within 3 s.e. and every run finite.  Why 3 and not 2: the kernels are
-deterministic but every kernel change re-rolls all 24 chaotic trajectories, and four comparisons at 2 s.e. would flag an
+deterministic but every kernel change re-rolls all 48 chaotic trajectories, and four comparisons at 2 s.e. would flag an
 exact implementation one change in six (it happened: HIP seeds 0..11 alone sat 2.1 s.e. below the reference's min loss, seeds
-0..47 sit at 1.3 s.e., tools/snr_spread_gpu.py)."""
+0..47 sit at 1.4 s.e.)."""
 import os
 
 import numpy as np
@@ -22,7 +22,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "snr_spread.npz")
-N_SEEDS_HIP = 24
+N_SEEDS_HIP = 48
 ALARM = 3.0          # standard errors, see the module docstring
 
 
