@@ -22,7 +22,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "snr_spread.npz")
-N_SEEDS_HIP = 48
+N_SEEDS_HIP = int(os.environ.get("DPI_SNR_SEEDS", "24"))   # 48 (all the reference's seeds) is the run recorded in DESIGN.md §4: +0.22 dB, 2 s.e. 0.34;
+                                                            # the default keeps the GPU suite near six minutes (24 seeds: +0.31 dB, 2 s.e. 0.40)
 ALARM = 3.0          # standard errors, see the module docstring
 
 
