@@ -1,11 +1,68 @@
 """Synthetic seismic-like volumes for benchmarks and parity runs (the reference's hyperbolic3d dataset is absent
-from its checkout): a (t, x, y) cube of hyperbolic events with a Ricker wavelet, apex at (x,y)=(0,0)."""
+from its checkout).
+
+`hyperbolic_volume` is the stand-in for `datasets/hyperbolic3d/original.npy` drawn after the figures and printed numbers of
+the reference's notebook (proof_of_concept_3D.ipynb cells 13 / 15 / 20): a (t, x, y) cube of hyperbolic events with apex at
+(x, y) = (0, 0); at the notebook's patch size (256, 128, 128) the first event has its apex near t = 50 and reaches the far
+corner near t = 250, the following events come 18-32 samples apart and fill everything below the first one, the wavelet is a
+Ricker whose central lobe is ~8 samples wide, and `std(gain * img * mask)` at gain 40 with 66 % of the traces missing is
+3.94 / 5.16 on the notebook's two patches (cell 15 output) — the amplitude is scaled so that the stand-in lands in that band.
+A weak band-limited background (2 % of the event RMS x 5; no exact zeros) keeps the empty part of the cube from being an
+exactly-zero target.  Smaller volumes are the same picture at a coarser sampling (wavelet and spacing scale with nt / 256,
+down to a quarter), so that (128, 64, 64) or (48, 32, 32) stand-ins hold as many events as the full patch.
+
+`sparse_hyperbolic_volume` is the round-1/2 stand-in (5 narrow events, > 70 % of the cube exactly zero, std 1.5 at the
+bench patch): kept because committed reference recordings (`tests/golden/plateau_96x64x64.npz`) were made on it."""
 import numpy as np
 
-__all__ = ["hyperbolic_volume", "random_trace_mask"]
+__all__ = ["hyperbolic_volume", "sparse_hyperbolic_volume", "random_trace_mask", "coarse_std"]
+
+TARGET_RMS = 0.19          # std of the un-gained cube: 40 * 0.19 * sqrt(0.34) = 4.4, the middle of the notebook's 3.94 .. 5.16
 
 
-def hyperbolic_volume(shape, seed=0, nev=5, dtype=np.float32):
+def _binomial_smooth(a, passes):
+    """Separable [1 4 6 4 1] / 16 low-pass along every axis, `passes` times (numpy only; zero-padded edges)."""
+    k = np.array([1.0, 4.0, 6.0, 4.0, 1.0], dtype=np.float32) / 16.0
+    for ax in range(a.ndim):
+        n = a.shape[ax]
+        for _ in range(passes):
+            p = np.zeros_like(a)
+            for j, w in enumerate(k):
+                s = j - 2
+                src = [slice(None)] * a.ndim
+                dst = [slice(None)] * a.ndim
+                src[ax] = slice(max(0, s), n + min(0, s))
+                dst[ax] = slice(max(0, -s), n - max(0, s))
+                p[tuple(dst)] += w * a[tuple(src)]
+            a = p
+    return a
+
+
+def hyperbolic_volume(shape, seed=0, background=0.02, dtype=np.float32):
+    rng = np.random.RandomState(seed)
+    nt, nx, ny = shape
+    s = min(1.0, max(0.25, nt / 256.0))          # sampling relative to the notebook's patch
+    f0 = 0.055 / s                               # Ricker peak frequency, cycles per sample
+    t = np.arange(nt, dtype=np.float32)[:, None, None]
+    r2 = (np.arange(nx, dtype=np.float32)[None, :, None] / max(nx, 1)) ** 2 + \
+         (np.arange(ny, dtype=np.float32)[None, None, :] / max(ny, 1)) ** 2
+    vol = np.zeros(shape, dtype=np.float32)
+    t0 = rng.uniform(0.12, 0.22) * nt
+    while t0 < 1.05 * nt:
+        c = 0.9 - 0.3 * min(t0 / nt, 1.0) + rng.uniform(-0.04, 0.04)     # moveout: slower (steeper) events on top
+        amp = rng.uniform(0.5, 1.0) * rng.choice([-1.0, 1.0])
+        tt = np.sqrt(t0 ** 2 + r2 * (nt * c) ** 2)
+        a = (np.pi * f0 * (t - tt)) ** 2
+        vol += (amp * (1.0 - 2.0 * a) * np.exp(-a)).astype(np.float32)
+        t0 += rng.uniform(18.0, 32.0) * s
+    vol *= TARGET_RMS / max(float(vol.std()), 1e-12)
+    if background > 0:
+        n = _binomial_smooth(rng.standard_normal(shape).astype(np.float32), 2)
+        vol += (background * 5.0 * TARGET_RMS / max(float(n.std()), 1e-12)) * n
+    return vol.astype(dtype)
+
+
+def sparse_hyperbolic_volume(shape, seed=0, nev=5, dtype=np.float32):
     rng = np.random.RandomState(seed)
     nt, nx, ny = shape
     t = np.arange(nt, dtype=np.float32)[:, None, None]
@@ -29,3 +86,8 @@ def random_trace_mask(shape, rate, seed=0, dtype=np.float32):
     keep = np.ones(ntr, dtype=dtype)
     keep[rng.choice(ntr, int(ntr * rate), replace=False)] = 0
     return np.broadcast_to(keep.reshape((1,) + tuple(shape[1:])), shape).copy()
+
+
+def coarse_std(vol, mask, gain=40.0):
+    """What the reference prints as "the std of coarse data" (main.py:118-139 `load_data`: unbiased std of img * mask)."""
+    return float(np.std(np.asarray(vol, dtype=np.float64) * gain * np.asarray(mask, dtype=np.float64), ddof=1))

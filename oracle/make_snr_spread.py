@@ -4,11 +4,17 @@
     cd /tmp && python /root/repo/oracle/make_snr_spread.py --merge                        (-> tests/golden/snr_spread.npz)
     cd /tmp && python /root/repo/oracle/make_snr_spread.py --plateau 96 64 64 --seeds 0 --epochs 600 --threads 8
                                                                                   (-> tests/golden/plateau_96x64x64.npz)
+    cd /tmp && python /root/repo/oracle/make_snr_spread.py --mid 128 64 64 --seeds 0 --epochs 1000 --threads 2   (one process per seed)
+    cd /tmp && python /root/repo/oracle/make_snr_spread.py --mid 128 64 64 --merge             (-> tests/golden/snr_mid_128x64x64.npz)
 
 Drives the reference `Interpolator` (imported from /root/reference through oracle/ref_shim.py, exactly as
 proof_of_concept_3D.ipynb cell 15 does) on the (48,32,32) hyperbolic stand-in: default MulResUnet3D (5 923 614
 parameters), 66 % random missing traces, gain 40, MAE, trilinear, param_noise=False, 1000 Adam iterations, one run per
 seed (`u.set_seed(seed)` before build_model: weights, z and the per-iteration noise all follow from it).
+`--mid NT NX NY` (round 3) records the same protocol at a size whose full-resolution level dispatches the big-tile kernels of the
+HIP path, on the notebook-like stand-in (`utils.synthetic.hyperbolic_volume`, std of the coarse data 4.4 as in
+proof_of_concept_3D.ipynb:355,362); a run writes its history every 25 iterations (`_snr_mid_parts/seedNNN.npz`, `done` = 0 until the
+last iteration), so that an interrupted recording still pins the trajectory up to where it got.
 Recorded per seed: loss / SNR / PCORR history, SNR(out_best), min and final loss.  The committed .npz holds data only
 (the volume, the mask and those numbers); initial weights are NOT stored — `init_weights` under the same seed is
 bit-identical between the reference and the build (tests/test_host.py::test_same_seed_init_is_bit_identical).
@@ -36,10 +42,11 @@ ARGV = ["--imgdir", "/nonexistent", "--datadim", "3d", "--net", "multiunet", "--
         "--loss", "mae", "--lr", "1e-3", "--gain", "40", "--reg_noise_std", "0.03", "--noise_std", "0.1"]
 
 
-def stand_in(shape=SHAPE):
-    """The volume/mask every seed shares (ours: deep_prior_interpolation_amd.utils.synthetic)."""
-    from deep_prior_interpolation_amd.utils.synthetic import hyperbolic_volume, random_trace_mask
-    vol = hyperbolic_volume(shape, seed=0).astype(np.float64)
+def stand_in(shape=SHAPE, dense=False):
+    """The volume/mask every seed shares (ours: deep_prior_interpolation_amd.utils.synthetic).  dense=False: the sparse 5-event cube
+    the (48,32,32) and plateau fixtures of rounds 1-2 were recorded on; dense=True: the notebook-like stand-in (round 3)."""
+    from deep_prior_interpolation_amd.utils.synthetic import hyperbolic_volume, random_trace_mask, sparse_hyperbolic_volume
+    vol = (hyperbolic_volume if dense else sparse_hyperbolic_volume)(shape, seed=0).astype(np.float64)
     mask = random_trace_mask(shape, 0.66, seed=1).astype(np.float64)
     return vol, mask
 
@@ -48,31 +55,50 @@ def snr_db(out, target):
     return 10.0 * np.log10(np.sum(target ** 2) / np.sum((target - out) ** 2))
 
 
-def run_seed(seed, epochs, threads, shape=SHAPE, save=True):
+def run_seed(seed, epochs, threads, shape=SHAPE, save=True, dense=False, part_dir=None, every=25):
     torch.set_num_threads(threads)
     main = ref_shim.load_main()
     import utils as u  # reference module
     args = ref_shim.parse_args(ARGV + ["--epochs", str(epochs)])
     args.param_noise = False
-    vol, mask = stand_in(shape)
+    vol, mask = stand_in(shape, dense)
     image = (vol * args.gain)[..., None]
     u.set_seed(seed)
     T = main.Interpolator(args, tempfile.mkdtemp())
     t0 = time.time()
+    part_dir = part_dir or PART
+
+    def record(done):
+        ob = np.asarray(T.out_best, dtype=np.float64) if T.out_best is not None else None
+        d = {"seed": np.int64(seed), "threads": np.int64(threads), "epochs": np.int64(epochs), "std": np.float64(std),
+             "loss": np.array(T.history.loss), "snr": np.array(T.history.snr), "pcorr": np.array(T.history.pcorr),
+             "snr_out_best": np.float64(snr_db(ob, image[..., 0])) if ob is not None else np.float64("nan"),
+             "loss_min": np.float64(T.loss_min if T.loss_min is not None else np.nan),
+             "argmin": np.int64(int(np.argmin(T.history.loss))) if len(T.history.loss) else np.int64(-1),
+             "seconds": np.float64(time.time() - t0), "done": np.int64(done)}
+        if save:
+            os.makedirs(part_dir, exist_ok=True)
+            tmp = os.path.join(part_dir, "seed%03d.tmp.npz" % seed)
+            np.savez_compressed(tmp, **d)
+            os.replace(tmp, os.path.join(part_dir, "seed%03d.npz" % seed))
+        return d
+    if every:
+        # checkpoint the history while the reference's own loop runs (main.py:209-217 calls optimization_loop once per iteration)
+        inner = T.optimization_loop
+
+        def loop_and_checkpoint(*a, **k):
+            r = inner(*a, **k)
+            if T.iiter % every == 0:
+                record(0)
+            return r
+        T.optimization_loop = loop_and_checkpoint
     with redirect_stdout(io.StringIO()):
         std = T.load_data({"image": image, "mask": mask[..., None], "name": "0"})
         T.build_model()
         T.build_input()
         T.optimize()
     dt = time.time() - t0
-    out_best = np.asarray(T.out_best, dtype=np.float64)
-    d = {"seed": np.int64(seed), "threads": np.int64(threads), "epochs": np.int64(epochs), "std": np.float64(std),
-         "loss": np.array(T.history.loss), "snr": np.array(T.history.snr), "pcorr": np.array(T.history.pcorr),
-         "snr_out_best": np.float64(snr_db(out_best, image[..., 0])), "loss_min": np.float64(T.loss_min),
-         "argmin": np.int64(int(np.argmin(T.history.loss))), "seconds": np.float64(dt)}
-    if save:
-        os.makedirs(PART, exist_ok=True)
-        np.savez_compressed(os.path.join(PART, "seed%03d.npz" % seed), **d)
+    d = record(1)
     print("seed %d: %.0f s, SNR(out_best) %.2f dB, min loss %.3e, final loss %.3e" %
           (seed, dt, d["snr_out_best"], d["loss_min"], d["loss"][-1]), flush=True)
     return d
@@ -83,7 +109,7 @@ def plateau(shape, seeds, epochs, threads):
     takes to leave it at a larger volume — the iteration count grows with the volume (SNR stays at 0 dB for ~150 iterations at
     (48,32,32)), and it decides what a 3000-iteration run at 256x128x128 reaches.  Records the reference's loss / SNR history."""
     import hashlib
-    parts = [run_seed(s, epochs, threads, shape=tuple(shape), save=False) for s in seeds]
+    parts = [run_seed(s, epochs, threads, shape=tuple(shape), save=False, every=0) for s in seeds]
     vol, mask = stand_in(tuple(shape))
     out = {"shape": np.array(shape), "argv": np.array(" ".join(ARGV)), "torch": np.array(torch.__version__),
            "volume_sha1": np.array(hashlib.sha1(vol.astype(np.float32).tobytes()).hexdigest()),
@@ -97,6 +123,28 @@ def plateau(shape, seeds, epochs, threads):
     for p in parts:
         esc = int(np.argmax(p["snr"] > 1.0)) if (p["snr"] > 1.0).any() else -1
         print("seed %d: first iteration with SNR > 1 dB: %d" % (p["seed"], esc))
+
+
+def merge_mid(shape):
+    """-> tests/golden/snr_mid_<shape>.npz from the per-seed parts (complete or not: `iterations` says how far each seed got)."""
+    import hashlib
+    tag = "x".join(str(n) for n in shape)
+    files = sorted(glob.glob(os.path.join(OUT, "_snr_mid_parts", "seed*.npz")))
+    files = [f for f in files if ".tmp." not in f]
+    parts = [dict(np.load(f)) for f in files]
+    n = min(len(p["loss"]) for p in parts)
+    vol, mask = stand_in(tuple(shape), dense=True)
+    out = {"shape": np.array(shape), "argv": np.array(" ".join(ARGV)), "torch": np.array(torch.__version__),
+           "stand_in": np.array("utils.synthetic.hyperbolic_volume(shape, seed=0), random_trace_mask(shape, 0.66, seed=1)"),
+           "volume_sha1": np.array(hashlib.sha1(vol.astype(np.float32).tobytes()).hexdigest()),
+           "mask_sha1": np.array(hashlib.sha1(mask.astype(np.uint8).tobytes()).hexdigest()),
+           "iterations": np.array([len(p["loss"]) for p in parts])}
+    for k in ("seed", "threads", "epochs", "std", "snr_out_best", "loss_min", "argmin", "seconds", "done"):
+        out[k] = np.array([p[k] for p in parts])
+    for k in ("loss", "snr", "pcorr"):
+        out[k] = np.stack([p[k][:n] for p in parts]).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "snr_mid_%s.npz" % tag), **out)
+    print("merged %d seeds at %s, %d common iterations; SNR(out_best) so far %s" % (len(parts), tag, n, np.round(out["snr_out_best"], 2)))
 
 
 def merge():
@@ -122,8 +170,16 @@ if __name__ == "__main__":
     ap.add_argument("--epochs", type=int, default=1000)
     ap.add_argument("--merge", action="store_true")
     ap.add_argument("--plateau", type=int, nargs=3, default=None, metavar=("NT", "NX", "NY"))
+    ap.add_argument("--mid", type=int, nargs=3, default=None, metavar=("NT", "NX", "NY"))
     a = ap.parse_args()
+    if a.mid and a.merge:
+        merge_mid(a.mid)
+        sys.exit(0)
     ref_shim.install()
+    if a.mid:
+        for s in a.seeds:
+            run_seed(s, a.epochs, a.threads, shape=tuple(a.mid), dense=True, part_dir=os.path.join(OUT, "_snr_mid_parts"))
+        sys.exit(0)
     if a.plateau:
         plateau(a.plateau, a.seeds or [0], a.epochs, a.threads)
         sys.exit(0)

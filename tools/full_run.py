@@ -24,9 +24,10 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--missing", type=float, default=0.66)
     ap.add_argument("--mode", default="auto")
-    ap.add_argument("--events", type=int, default=0, help="hyperbolic events in the stand-in; 0 = one per 8 time samples (the density "
-                    "of the (48,32,32) SNR-protocol volume; 5 events in 256 samples leave > 90 %% of the cube at zero and MAE then sits "
-                    "on the all-zero median plateau for 1700-2700 iterations before it starts to fit, see DESIGN.md §4)")
+    ap.add_argument("--sparse-events", type=int, default=0, help="> 0: the round-1/2 stand-in (`sparse_hyperbolic_volume`) with this many "
+                    "narrow events instead of the notebook-like cube (`hyperbolic_volume`, utils/synthetic.py)")
+    ap.add_argument("--background", type=float, default=0.02, help="weak band-limited background of the stand-in (0 = exact zeros above the first event)")
+    ap.add_argument("--precision", default="fp32")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "full_run.json"))
     a = ap.parse_args()
     from deep_prior_interpolation_amd import utils as u
@@ -34,10 +35,12 @@ def main():
     from deep_prior_interpolation_amd.parameter import parse_arguments
     args = parse_arguments(["--imgdir", "synthetic", "--datadim", "3d", "--net", "multiunet", "--inputdepth", "64", "--upsample", "linear",
                             "--loss", "mae", "--lr", "1e-3", "--gain", "40", "--reg_noise_std", "0.03", "--noise_std", "0.1",
-                            "--epochs", str(a.epochs), "--gpu", "0"])
+                            "--epochs", str(a.epochs), "--gpu", "0", "--precision", a.precision])
     shape = tuple(a.patch)
-    nev = a.events if a.events > 0 else max(5, shape[0] // 8)
-    vol = u.hyperbolic_volume(shape, seed=0, nev=nev)
+    if a.sparse_events > 0:
+        vol = u.sparse_hyperbolic_volume(shape, seed=0, nev=a.sparse_events)
+    else:
+        vol = u.hyperbolic_volume(shape, seed=0, background=a.background)
     mask = u.random_trace_mask(shape, a.missing, seed=1)
     u.set_seed(a.seed)
     T = Interpolator(args, "/tmp", seed=a.seed)
@@ -54,7 +57,8 @@ def main():
     snr_best = 10.0 * np.log10(np.sum(target ** 2) / np.sum((target - ob) ** 2))
     h = T.history
     every = max(1, a.epochs // 300)
-    res = {"patch": list(shape), "events": nev, "epochs": len(h.loss), "seed": a.seed, "missing_traces": a.missing, "std_masked": std,
+    res = {"patch": list(shape), "stand_in": ("sparse, %d events" % a.sparse_events) if a.sparse_events > 0 else "notebook-like, background %g" % a.background,
+           "precision": a.precision, "epochs": len(h.loss), "seed": a.seed, "missing_traces": a.missing, "std_masked": std,
            "seconds": round(dt, 2), "it_per_s": round(len(h.loss) / dt, 3), "num_params": T.num_params,
            "finite": bool(np.isfinite(h.loss).all() and np.isfinite(ob).all()),
            "snr_out_best_db": float(snr_best), "loss_min": float(np.min(h.loss)), "argmin": int(np.argmin(h.loss)),
