@@ -15,9 +15,16 @@ class DpiError(RuntimeError):
     pass
 
 
+ABI_VERSION = 300      # include/dpi_hip.h as of round 3: dpi_conv_desc starts with its own size
+
+
 class ConvDesc(C.Structure):
-    _fields_ = [("Cin", C.c_int), ("Cout", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
+    """dpi_conv_desc.  ConvDesc(Cin, Cout, D, H, W, k, kd, stride, precision) fills the leading `size` field itself."""
+    _fields_ = [("size", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("k", C.c_int), ("kd", C.c_int), ("stride", C.c_int), ("precision", C.c_int)]
+
+    def __init__(self, Cin=0, Cout=0, D=1, H=1, W=1, k=1, kd=1, stride=1, precision=0):
+        super().__init__(C.sizeof(ConvDesc), int(Cin), int(Cout), int(D), int(H), int(W), int(k), int(kd), int(stride), int(precision))
 
 
 class AdamTensor(C.Structure):
@@ -35,6 +42,7 @@ _DESC = C.POINTER(ConvDesc)
 SIGNATURES = {
     "dpi_last_error": (C.c_char_p, []),
     "dpi_version": (_I, []),
+    "dpi_conv_desc_size": (_I, []),
     "dpi_device_info": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_Z), C.c_char_p, _I]),
     "dpi_profile_marker": (_I, [_I, _P]),
     "dpi_set_bw_tuning": (None, [_I, _I]),
@@ -115,6 +123,9 @@ def load():
             raise DpiError("libdpi_hip.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
+    if lib.dpi_version() < ABI_VERSION or lib.dpi_conv_desc_size() != C.sizeof(ConvDesc):
+        raise DpiError("libdpi_hip.so is ABI version %d with a %d-byte dpi_conv_desc; this binding needs >= %d and %d bytes (stale build? "
+                       "re-run __graft_entry__.build())" % (lib.dpi_version(), lib.dpi_conv_desc_size(), ABI_VERSION, C.sizeof(ConvDesc)))
     _lib = lib
     return lib
 

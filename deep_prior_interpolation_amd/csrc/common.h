@@ -9,6 +9,8 @@
 
 void dpi_set_error(const char* fmt, ...);
 int dpi_check_launch(const char* what);
+// Validates a caller's descriptor (size field first: a binding built against another struct layout is rejected, not read past).
+int dpi_check_conv_desc(const dpi_conv_desc* d);
 
 #define DPI_REQUIRE(cond, ...)            \
   do {                                    \

@@ -290,7 +290,7 @@ BwPlan plan(const dpi_conv_desc* d) {
 }  // namespace
 
 extern "C" size_t dpi_conv_bwd_weight_ws_floats(const dpi_conv_desc* d) {
-  if (!d || d->Cin <= 0 || d->Cout <= 0) return 0;
+  if (dpi_check_conv_desc(d) != DPI_OK) return 0;
   if (dpi_conv_bf16_bww_usable(d)) {          // the fp32 kernels stay the fallback for unaligned views: size for both
     dpi_conv_desc f = *d;
     f.precision = 0;
@@ -307,7 +307,8 @@ extern "C" size_t dpi_conv_bwd_weight_ws_floats(const dpi_conv_desc* d) {
 
 extern "C" int dpi_conv_bwd_weight(const dpi_conv_desc* d, const float* x, const float* x_chain, const float* dy,
                                    float* dw, float* ws, size_t ws_floats, void* stream) {
-  DPI_REQUIRE(d && x && dy && dw && ws, "conv_bwd_weight: null argument");
+  if (int e = dpi_check_conv_desc(d)) return e;
+  DPI_REQUIRE(x && dy && dw && ws, "conv_bwd_weight: null argument");
   DPI_REQUIRE((d->k == 1 || d->k == 3) && (d->kd == d->k || d->kd == 1) && (d->stride == 1 || d->stride == 2),
               "conv_bwd_weight: unsupported k=%d kd=%d stride=%d", d->k, d->kd, d->stride);
   hipStream_t st = (hipStream_t)stream;

@@ -419,8 +419,14 @@ void launch_pw_co(const PwArgs& a, int co_b, dim3 grid, hipStream_t st) {
   }
 }
 
-int check_desc(const dpi_conv_desc* d) {
+int check_desc(const dpi_conv_desc* d) { return dpi_check_conv_desc(d); }
+
+}  // namespace
+
+int dpi_check_conv_desc(const dpi_conv_desc* d) {
   DPI_REQUIRE(d, "conv: null descriptor");
+  DPI_REQUIRE(d->size == (int)sizeof(dpi_conv_desc), "conv: descriptor size field is %d, this library's dpi_conv_desc has %d bytes (stale binding? "
+              "set desc.size = sizeof(dpi_conv_desc) of the header you compiled against; dpi_conv_desc_size() gives the library's)", d->size, (int)sizeof(dpi_conv_desc));
   DPI_REQUIRE(d->Cin > 0 && d->Cout > 0 && d->D > 0 && d->H > 0 && d->W > 0, "conv: non-positive dims");
   DPI_REQUIRE(d->k == 1 || d->k == 3, "conv: k must be 1 or 3 (got %d)", d->k);
   DPI_REQUIRE(d->kd == d->k || d->kd == 1, "conv: kd must be k (3-D) or 1 (2-D), got %d", d->kd);
@@ -433,8 +439,6 @@ int check_desc(const dpi_conv_desc* d) {
   DPI_REQUIRE(d->precision >= 0 && d->precision <= 2, "conv: precision must be 0 (fp32), 1 (bf16 operands) or 2 (three-term bf16 split), got %d", d->precision);
   return DPI_OK;
 }
-
-}  // namespace
 
 // MFMA stencil path (conv_mfma.hip): k = 3, stride 1, enough output channels to fill a 16-row MFMA tile
 int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,

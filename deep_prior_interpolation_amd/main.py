@@ -135,7 +135,17 @@ class Interpolator:
         """(1,1,T,X,Y) -> (T,X,Y) ; (1,C,H,W) -> (H,W,C)  (main.py:175-176)."""
         return u.torch_to_np(out_, True) if out_.ndim > 4 else u.torch_to_np(out_, False)[0].transpose((1, 2, 0))
 
+    def apply_precision(self):
+        """--precision of THIS Interpolator becomes the arithmetic mode of the convolutions launched from here on (ops.PRECISION is
+        read when a layer builds its descriptor).  Called at the top of every iteration, eager or captured, so that the mode never
+        depends on which Interpolator ran before in the process (DPI_PRECISION in the environment is a tools-only override of the
+        default)."""
+        prec = getattr(self.args, "precision", "fp32")
+        if prec != "fp32" or "DPI_PRECISION" not in os.environ:
+            ops.set_precision(prec)
+
     def optimization_loop(self, net_input=None):
+        self.apply_precision()
         input_ = self.perturbed_input() if net_input is None else net_input
         if self.iiter < self.args.data_forgetting_factor:       # main.py:153-155
             if input_ is self.input_ or net_input is not None:
@@ -211,8 +221,6 @@ class Interpolator:
             mode = "eager" if (net_inputs is not None or a.save_every is not None or a.epochs < 3 or self.has_regularizer()
                                or a.data_forgetting_factor != 0 or int(np.prod(self.img.shape[:-1])) >= (1 << 20)) else "graph"
         self.optimizer = FusedAdam(self.net.parameters(), lr=a.lr)
-        if getattr(a, "precision", "fp32") != "fp32" or "DPI_PRECISION" not in os.environ:     # (the environment variable is a tools-only override)
-            ops.set_precision(getattr(a, "precision", "fp32"))
         ops.set_weight_grad_overlap(mode == "eager" and int(np.prod(self.img.shape[:-1])) >= (1 << 20))
         start = time()
         if mode == "graph":
@@ -254,6 +262,7 @@ class Interpolator:
         kind = self.loss_kind
 
         def one_iteration():
+            self.apply_precision()
             opt.zero_grad()
             out_ = self.net(self.perturbed_input())
             loss, metrics = ops.masked_loss(out_, self.img_, self.mask_, kind)

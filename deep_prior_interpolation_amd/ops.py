@@ -77,14 +77,21 @@ def desc_out_dims(d):
 # ------------------------------------------------------------------------------------------------
 class KernelTimer:
     """Brackets selected launches with HIP events on the stream they are launched on (torch's current stream),
-    for bench.py's roofline line.  `match(kind, desc)` selects launches; durations() gives milliseconds."""
+    for bench.py's roofline line.  `match(kind, desc)` selects launches: a falsy result skips the launch, anything else is
+    the key the launch is filed under.  durations() gives all milliseconds, by_key() groups them."""
 
     def __init__(self, match):
         self.match = match
         self.events = []
 
     def durations(self):
-        return [a.elapsed_time(b) for a, b in self.events]
+        return [a.elapsed_time(b) for _, a, b in self.events]
+
+    def by_key(self):
+        out = {}
+        for key, a, b in self.events:
+            out.setdefault(key, []).append(a.elapsed_time(b))
+        return out
 
 
 _timer = None
@@ -127,12 +134,13 @@ def _timed(kind, d, launch):
         launch()
         L.dpi_profile_marker(1, stream())
         return
-    if _timer is not None and _timer.match(kind, d):
+    key = _timer.match(kind, d) if _timer is not None else None
+    if key:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         launch()
         e1.record()
-        _timer.events.append((e0, e1))
+        _timer.events.append((key, e0, e1))
     else:
         launch()
 

@@ -4,7 +4,10 @@ Patches are independent optimisations (reference main.py:274-295 iterates them s
 indices from a shared counter (PatchQueue: an atomic fetch-add on torch.distributed's store — no data-path collective;
 skipped or early-stopped patches therefore never idle a rank; DPI_STATIC_SHARD=1 restores the static p mod W split).
 Every patch seeds its own weights / z / noise stream from its index (Interpolator.begin_patch), so a patch's result does
-not depend on the rank, the world size or the schedule.  The only exchange is the
+not depend on the rank, the world size or the schedule — except with --start_from_prev, where a patch starts from the net of
+the patch its Interpolator optimised before (reference main.py:286): that chain is only defined per process, so the flag forces
+the static `p mod W` shard and one patch at a time per GPU, which makes the chains reproducible for a given W.
+The only exchange is the
 final reassembly (reference data.reconstruct_patches, data.py:87-130): every rank overlap-adds its best outputs
 into a local full-volume accumulator and ONE all-reduce(sum) of that fp32 volume (RCCL over xGMI; gloo in the
 CPU tests) followed by the analytic hit-count normalisation gives every rank the reconstructed volume.
@@ -43,10 +46,10 @@ class PatchQueue:
         self._static = None if static is None else shard_indices(self.num, *static)
 
     @classmethod
-    def for_process_group(cls, num, key="dpi/next_patch"):
+    def for_process_group(cls, num, key="dpi/next_patch", static=False):
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if os.environ.get("DPI_STATIC_SHARD", "0") == "1":
+        if static or os.environ.get("DPI_STATIC_SHARD", "0") == "1":
             return cls(num, static=(rank, world))
         if world > 1:
             from torch.distributed import distributed_c10d
@@ -153,7 +156,13 @@ def optimise_volume(args, patches, origins, vol_shape, pe, device, outpath=None,
     from .main import Interpolator, optimize_concurrently
     cropped = u.in_content_cropped_shape(vol_shape, pe.dim, pe.stride)
     acc = DeviceOverlapAccumulator(cropped, pe.dim, pe.stride, device)
-    queue = queue or PatchQueue.for_process_group(len(patches))
+    if args.start_from_prev:
+        if conc > 1:
+            raise _lib.DpiError("--start_from_prev chains the patches of a process one after the other (reference main.py:286): "
+                                "it cannot be combined with DPI_CONCURRENT_PATCHES > 1")
+        if queue is not None and queue._static is None and (queue.store is not None):
+            raise _lib.DpiError("--start_from_prev needs the static patch shard (a shared queue would make the warm-start chain depend on timing)")
+    queue = queue or PatchQueue.for_process_group(len(patches), static=bool(args.start_from_prev))
     Ts = [Interpolator(args, outpath, device=device) for _ in range(max(conc, 1))]
     mine = []
     t_setup = t_loop = 0.0
@@ -171,7 +180,7 @@ def optimise_volume(args, patches, origins, vol_shape, pe, device, outpath=None,
                 continue
             T.begin_patch(i)
             if T.net is None or not args.start_from_prev:
-                T.build_model()
+                T.build_model(netpath=args.netdir[i]) if len(args.netdir) != 0 else T.build_model()
             T.build_input()
             T.build_regularizer()
             if len(Ts) > 1 and T.graph_capable():
@@ -226,7 +235,7 @@ def main(argv=None):
     pe = patch_extractor_for(vol.shape, args.patch_shape, args.patch_stride, args.datadim, args.imgchannel)
     origins = u.window_origins(vol.shape, pe.dim, pe.stride)
     conc = int(os.environ.get("DPI_CONCURRENT_PATCHES", "1"))
-    queue = PatchQueue.for_process_group(len(patches))
+    queue = PatchQueue.for_process_group(len(patches), static=bool(args.start_from_prev))
     if args.datadim == "3d" and vol.ndim == 3:
         if (args.imgchannel or 1) != 1:
             raise _lib.DpiError("the device overlap-add path re-assembles single-channel 3-D volumes (imgchannel = 1)")
@@ -247,7 +256,7 @@ def main(argv=None):
             else:
                 T.begin_patch(i)
                 if T.net is None or not args.start_from_prev:
-                    T.build_model()
+                    T.build_model(netpath=args.netdir[i]) if len(args.netdir) != 0 else T.build_model()
                 T.build_input()
                 T.build_regularizer()
                 T.optimize(verbose=False)

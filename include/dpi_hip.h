@@ -43,6 +43,8 @@ extern "C" {
 #define DPI_CHAIN_STRIDE 5
 
 const char* dpi_last_error(void);
+/* ABI version: 300 = round 3 (dpi_conv_desc carries its own size as first field).  A binding checks `>=` the version it was
+ * written against and dpi_conv_desc_size() == its own struct size. */
 int dpi_version(void);
 /* Number of devices / properties as HIP sees them (no torch involved). */
 int dpi_device_info(int device, int* cus, int* lds_bytes, size_t* hbm_bytes, char* name, int name_len);
@@ -64,6 +66,10 @@ void dpi_set_bf16_debug(int flags);
  * kd = k for 3-D, kd = 1 for 2-D (D must be 1).
  */
 typedef struct {
+  /* = sizeof(dpi_conv_desc) of the header the CALLER was built against (dpi_conv_desc_size() gives the library's).  Every entry
+   * point that takes a descriptor rejects a mismatch with DPI_E_ARG instead of reading fields past a shorter struct: the
+   * descriptor grew a `precision` field in round 2 and a binding with the old 8-int layout read it from adjacent memory. */
+  int size;
   int Cin, Cout;
   int D, H, W;      /* input spatial size */
   int k, kd;        /* kernel extent in H/W and in D */
@@ -75,6 +81,8 @@ typedef struct {
    * accumulated in fp32: fp32-class accuracy (same tolerance as precision 0 against the fp64 oracle) on the bf16 matrix cores. */
   int precision;
 } dpi_conv_desc;
+/* sizeof(dpi_conv_desc) as the library was compiled; a binding asserts it equals its own struct size at load time. */
+int dpi_conv_desc_size(void);
 
 /* number of stat-partial blocks dpi_conv_fwd writes for this problem (0 if desc invalid) */
 int dpi_conv_fwd_stat_blocks(const dpi_conv_desc* d);

@@ -109,3 +109,36 @@ def test_single_process_host_accumulator_matches_reference_reconstruct():
                               lambda i, p: p)
     np.testing.assert_allclose(rec, pe.reconstruct(pa), rtol=1e-14)
     assert mine == list(range(int(np.prod(pa.shape[:2]))))
+
+
+def _bench(*argv, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=e, capture_output=True, text=True, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_launcher_two_ranks():
+    """`python bench.py --gpus 2` as the driver calls it, WITHOUT torch.distributed.run around it: the script starts its own rank
+    processes, they rendezvous on 127.0.0.1, pull patches from the shared counter, all-reduce the accumulator, and rank 0's ONE
+    JSON line comes back with n_gpus = 2 (round 2: `--gpus` was parsed and never read; the line said n_gpus 1).  CPU stand-in
+    workload over gloo — the same launcher, queue and gather code the GPU workloads run."""
+    rc, out, err = _bench("--gpus", "2", "--workload", "selftest", "--steps", "2")
+    assert rc == 0, err
+    assert out["n_gpus"] == 2 and out["gather"]["rccl_ranks"] == 2 and out["gather"]["backend"] == "gloo"
+    assert sum(out["gather"]["patches_per_rank"]) == 5 and min(out["gather"]["patches_per_rank"]) >= 1
+    assert out["gather"]["reconstruction_exact"] is True
+    # under an external launcher (WORLD_SIZE set) the script is a plain rank and must not spawn again
+    rc, out, err = _bench("--gpus", "1", "--workload", "selftest", "--steps", "1")
+    assert rc == 0 and out["n_gpus"] == 1
+
+
+def test_bench_launcher_reports_failure():
+    """A rank that dies must make `bench.py --gpus N` exit non-zero instead of printing a line from the survivors."""
+    rc, out, err = _bench("--gpus", "2", "--workload", "c2", "--steps", "1", env={"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
+    assert rc != 0 and out is None

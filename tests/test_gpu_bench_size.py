@@ -192,7 +192,7 @@ def test_default_net_fused_vs_leaf_at_128x64x64():
     shape = (128, 64, 64)
     gen = torch.Generator(device=DEV).manual_seed(5)
     z = 0.1 * torch.randn((1, 64) + shape, device=DEV, generator=gen)
-    img = torch.from_numpy(u.hyperbolic_volume(shape, seed=0) * 40.0)[None, None].to(DEV)
+    img = torch.from_numpy(u.sparse_hyperbolic_volume(shape, seed=0) * 40.0)[None, None].to(DEV)
     mask = torch.from_numpy(u.random_trace_mask(shape, 0.66, seed=1))[None, None].to(DEV)
     res = []
     for fused, n in ((True, net), (False, net2)):

@@ -56,7 +56,7 @@ def _survey(tmp_path, shape=(32, 16, 16)):
     from deep_prior_interpolation_amd import utils as u
     d = tmp_path / "data"
     d.mkdir(exist_ok=True)
-    np.save(d / "original.npy", u.hyperbolic_volume(shape, seed=5).astype(np.float32))
+    np.save(d / "original.npy", u.sparse_hyperbolic_volume(shape, seed=5).astype(np.float32))
     np.save(d / "mask.npy", u.random_trace_mask(shape, 0.5, seed=6).astype(np.float32))
     return ["--imgdir", str(d), "--imgname", "original.npy", "--maskname", "mask.npy", "--datadim", "3d", "--patch_shape", "16", "16", "16",
             "--patch_stride", "16", "16", "16", "--filters", "4", "8", "--skip", "4", "--inputdepth", "8", "--upsample", "linear", "--gain", "2", "--gpu", "0"]
@@ -163,7 +163,7 @@ def test_pocs_regularised_loop(golden):
     from deep_prior_interpolation_amd import main_pocs, utils as u
     from deep_prior_interpolation_amd.parameter import parse_arguments
     shape = (16, 12, 20)
-    vol = u.hyperbolic_volume(shape, seed=2)[..., None] * 2.0
+    vol = u.sparse_hyperbolic_volume(shape, seed=2)[..., None] * 2.0
     mask = u.random_trace_mask(shape, 0.5, seed=3)[..., None].astype(np.float64)
     for weight in (None, 0.3):
         argv = ["--imgdir", "x", "--datadim", "3d", "--filters", "4", "8", "--skip", "4", "--inputdepth", "8", "--upsample", "linear",
@@ -266,7 +266,7 @@ def test_precision_modes_through_the_loop_at_awkward_shapes(shape):
     from deep_prior_interpolation_amd import ops, utils as u
     from deep_prior_interpolation_amd.main import Interpolator
     from deep_prior_interpolation_amd.parameter import parse_arguments
-    vol = u.hyperbolic_volume(shape, seed=3)
+    vol = u.sparse_hyperbolic_volume(shape, seed=3)
     mask = u.random_trace_mask(shape, 0.5, seed=4)
     losses = {}
     try:

@@ -252,7 +252,7 @@ def test_cli_end_to_end_single_and_multi_rank_driver_agree(tmp_path, monkeypatch
     from deep_prior_interpolation_amd.data import reconstruct_patches
     from deep_prior_interpolation_amd.parameter import parse_arguments
     shape = (40, 40, 40)
-    vol = u.hyperbolic_volume(shape, seed=5).astype(np.float32)
+    vol = u.sparse_hyperbolic_volume(shape, seed=5).astype(np.float32)
     mask = u.random_trace_mask(shape, 0.5, seed=6).astype(np.float32)
     d = tmp_path / "data"
     d.mkdir()
@@ -336,7 +336,7 @@ def test_snr_parity_with_oracle_over_a_longer_run():
     K, shape = 40, (24, 24, 32)
     args = parse_arguments(["--imgdir", "x", "--datadim", "3d", "--filters", "4", "8", "16", "--skip", "4", "8", "--inputdepth", "8",
                             "--upsample", "linear", "--epochs", str(K), "--gpu", "0", "--loss", "mae"])
-    vol = u.hyperbolic_volume(shape, seed=2)[..., None] * 40.0
+    vol = u.sparse_hyperbolic_volume(shape, seed=2)[..., None] * 40.0
     mask = u.random_trace_mask(shape, 0.5, seed=3)[..., None].astype(np.float64)
     u.set_seed(0)
     T = Interpolator(args, "/tmp")
@@ -373,7 +373,7 @@ def test_concurrent_patches_match_standalone_graph_run(tmp_path, monkeypatch):
     from deep_prior_interpolation_amd.parameter import parse_arguments
     args = parse_arguments(["--imgdir", "x", "--datadim", "3d", "--filters", "4", "8", "--skip", "4", "--inputdepth", "8",
                             "--upsample", "linear", "--epochs", "12", "--gpu", "0"])
-    vols = [u.hyperbolic_volume((24, 16, 32), seed=20 + k)[..., None] * 40.0 for k in range(3)]
+    vols = [u.sparse_hyperbolic_volume((24, 16, 32), seed=20 + k)[..., None] * 40.0 for k in range(3)]
     mask = u.random_trace_mask((24, 16, 32), 0.5, seed=9)[..., None].astype(np.float64)
 
     def prepared(k):
@@ -394,7 +394,7 @@ def test_concurrent_patches_match_standalone_graph_run(tmp_path, monkeypatch):
     shape = (40, 40, 40)
     d = tmp_path / "data"
     d.mkdir()
-    np.save(d / "original.npy", u.hyperbolic_volume(shape, seed=5).astype(np.float32))
+    np.save(d / "original.npy", u.sparse_hyperbolic_volume(shape, seed=5).astype(np.float32))
     np.save(d / "mask.npy", u.random_trace_mask(shape, 0.5, seed=6).astype(np.float32))
     monkeypatch.chdir(tmp_path)
     monkeypatch.setenv("DPI_CONCURRENT_PATCHES", "3")

@@ -654,3 +654,70 @@ def test_conv_bwd_weight_split_mode_has_fp32_accuracy(ops, cin, cout, shape, mon
         errs[prec] = rel(dw, wr.grad)
     assert errs[2] < 5e-6, errs
     assert errs[2] < 4 * errs[0] + 1e-7, errs
+
+
+def _integration_block():
+    """The ctypes binding printed in INTEGRATION.md §2, verbatim."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "INTEGRATION.md")) as fp:
+        text = fp.read()
+    sec = text[text.index("## 2. Calling the C ABI directly"):]
+    m = re.search(r"```python\n(.*?)```", sec, re.S)
+    assert m and "class ConvDesc" in m.group(1)
+    return root, m.group(1)
+
+
+def test_integration_md_binding_runs_verbatim(ops, monkeypatch):
+    """Row (b) of SURVEY §8: the reference-side binding a maintainer would add, as documented, against the built library — the
+    document's ConvDesc must be the header's dpi_conv_desc (round 2 shipped a document with the 8-int layout of round 1)."""
+    root, code = _integration_block()
+    monkeypatch.chdir(root)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#2", "exec"), ns)
+    g = torch.Generator().manual_seed(5)
+    for (cin, cout, shape, k, stride) in [(5, 9, (6, 10, 12), 3, 1), (7, 3, (8, 8, 40), 3, 2), (6, 11, (4, 6, 8), 1, 1)]:
+        x = torch.randn((1, cin) + shape, generator=g).to(DEV)
+        w = (0.2 * torch.randn((cout, cin, k, k, k), generator=g)).to(DEV)
+        b = torch.randn(cout, generator=g).to(DEV)
+        y = ns["conv3d_forward"](x, w, b, stride)
+        ref = ops.conv(x, w, b, stride)
+        assert y.shape == ref.shape and torch.equal(y, ref)
+        yo = O.conv_nd(x.cpu().double(), w.cpu().double(), b.cpu().double(), stride)
+        assert rel(y, yo) < 5e-6
+
+
+def test_stale_descriptor_layouts_are_rejected():
+    """A binding built against another dpi_conv_desc (the 8-int layout of round 1, or the 9-int one of round 2 without the
+    leading size) must get DPI_E_ARG and a message, not a convolution with `precision` read from adjacent memory."""
+    import ctypes as C
+    from deep_prior_interpolation_amd import _lib
+    L = _lib.load()
+    assert L.dpi_conv_desc_size() == C.sizeof(_lib.ConvDesc) == 40
+
+    class Old8(C.Structure):
+        _fields_ = [(n, C.c_int) for n in ("Cin", "Cout", "D", "H", "W", "k", "kd", "stride")]
+
+    class Old9(C.Structure):
+        _fields_ = [(n, C.c_int) for n in ("Cin", "Cout", "D", "H", "W", "k", "kd", "stride", "precision")]
+    x = torch.randn(1, 4, 4, 8, 8, device=DEV)
+    w = torch.randn(8, 4, 3, 3, 3, device=DEV)
+    y = torch.full((1, 8, 4, 8, 8), 7.0, device=DEV)
+    fwd = L.dpi_conv_fwd
+    saved = fwd.argtypes
+    fwd.argtypes = [C.c_void_p] * 8
+    try:
+        for d in (Old8(4, 8, 4, 8, 8, 3, 3, 1), Old9(4, 8, 4, 8, 8, 3, 3, 1, 0)):
+            buf = (C.c_char * 64)()                       # the short struct followed by zeros, as it would sit in a caller's frame
+            C.memmove(buf, C.byref(d), C.sizeof(d))
+            rc = fwd(C.addressof(buf), x.data_ptr(), None, w.data_ptr(), None, y.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+            assert rc == -1 and b"size" in L.dpi_last_error()
+        good = _lib.ConvDesc(4, 8, 4, 8, 8, 3, 3, 1, 0)
+        good.size = 36
+        assert fwd(C.addressof(good), x.data_ptr(), None, w.data_ptr(), None, y.data_ptr(), None, torch.cuda.current_stream().cuda_stream) == -1
+        assert L.dpi_conv_bwd_weight_ws_floats(C.byref(good)) == 0
+    finally:
+        fwd.argtypes = saved
+    torch.cuda.synchronize()
+    assert bool((y == 7.0).all())                         # nothing was launched
