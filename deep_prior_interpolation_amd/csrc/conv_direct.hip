@@ -445,6 +445,10 @@ int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain
                       double* partials, bool flip, int accumulate, hipStream_t st);
 void dpi_conv_pw_mfma_plan(size_t V, int cout, int* vox_per_block, int* mt);
 bool dpi_conv_fewco_usable(const dpi_conv_desc* d);
+bool dpi_conv_q4_usable(const dpi_conv_desc* d, bool flip);
+int dpi_conv_q4_tiles(const dpi_conv_desc* d, int* ntd, int* nth, int* ntw);
+int dpi_conv_q4_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
+                    double* partials, bool flip, int accumulate, hipStream_t st);
 int dpi_conv_fewco_tiles(const dpi_conv_desc* d, int* ntd, int* nth, int* ntw);
 int dpi_conv_fewco_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
                             double* partials, hipStream_t st);
@@ -475,6 +479,7 @@ extern "C" int dpi_conv_fwd_stat_blocks(const dpi_conv_desc* d) {
   int Do, Ho, Wo;
   dpi_conv_out_dims(d, &Do, &Ho, &Wo);
   if (dpi_conv_bf16_usable(d, false)) return dpi_conv_bf16_stat_blocks(d);
+  if (dpi_conv_q4_usable(d, false)) { int a, b, c; return dpi_conv_q4_tiles(d, &a, &b, &c); }
   if (d->k == 1 && d->Cout >= g_mfma_min_cout) {
     int vpb, mt;
     dpi_conv_pw_mfma_plan((size_t)Do * Ho * Wo, d->Cout, &vpb, &mt);
@@ -502,6 +507,7 @@ static int conv_run(const dpi_conv_desc* d, const float* x, const float* chain, 
   const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
   const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
   if (dpi_conv_bf16_usable(d, flip)) return dpi_conv_bf16_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
+  if (dpi_conv_q4_usable(d, flip)) return dpi_conv_q4_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
   if (d->k == 3 && cout >= g_mfma_min_cout && (d->stride == 1 || !flip))
     return dpi_conv_mfma_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
   if (d->k == 1 && cout >= g_mfma_min_cout) return dpi_conv_pw_mfma_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);

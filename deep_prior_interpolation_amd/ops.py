@@ -166,6 +166,7 @@ def raw_conv_bwd_data(d, dy, w, dx, accumulate=False):
 # 256x128x128) and costs host time when it is launch-bound (64^3 eager: 8.8 -> 11.3 ms).  Interpolator.optimize / bench.py
 # switch it on by patch size; DPI_OVERLAP_WGRAD=0/1 forces it.
 OVERLAP_WEIGHT_GRADS = os.environ.get("DPI_OVERLAP_WGRAD", "0") == "1"
+OVERLAP_MAX_VOXELS = int(os.environ.get("DPI_OVERLAP_MAX_VOXELS", str(1 << 40)))
 
 
 def set_weight_grad_overlap(on):
@@ -187,7 +188,9 @@ def _side_stream():
 def conv_bwd_weight_async(d, x, chain, dy, dw):
     """raw_conv_bwd_weight on the side stream (ordered after everything already queued on the current stream).
     Callers must `join_weight_grads()` before returning to autograd."""
-    if not OVERLAP_WEIGHT_GRADS or torch.cuda.is_current_stream_capturing():
+    # (DPI_OVERLAP_MAX_VOXELS: A/B knob — restricting the side stream to the coarse levels, whose kernels leave CUs idle, measured
+    #  35.76 ms per iteration against 35.10 with every layer on it, round 3)
+    if not OVERLAP_WEIGHT_GRADS or d.D * d.H * d.W >= OVERLAP_MAX_VOXELS or torch.cuda.is_current_stream_capturing():
         # (inside a hipGraph capture the fork / join edges cost more than the overlap wins on the small patches that are
         #  run as graphs: measured 7.6 vs 7.9 ms per iteration at 64^3)
         return raw_conv_bwd_weight(d, x, chain, dy, dw)

@@ -105,6 +105,10 @@ void dpi_set_bwd_weight_mfma_min_cout(int n);
 /* Tuning / test hook: 0 routes forward 3x3x3 convs with Cout <= 4 back to the VALU kernel instead of the (co, kw)-row
  * MFMA kernel (csrc/conv_fewco_mfma.hip). */
 void dpi_set_fewco_mfma(int on);
+/* Tuning / test hook of the 4x4x1-MFMA kernel for 3x3x3 stride-1 convolutions with <= 8 output channels (csrc/conv_q4_mfma.hip):
+ * on = 0 routes those shapes back to the 16x16x4 kernels, 1 (default) uses it where it pays, 2 wherever it can run (tests); < 0 keeps
+ * the setting; ck in {2, 4} = input channels per chunk (other values keep the setting). */
+void dpi_set_q4(int on, int ck);
 
 /* ---------------------------------------------------------------- BatchNorm / activations -------
  * Replaces nn.BatchNorm3d/2d in training mode (base.py:164,214; mulresunet.py:80-81,104,225) and

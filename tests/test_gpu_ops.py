@@ -721,3 +721,81 @@ def test_stale_descriptor_layouts_are_rejected():
         fwd.argtypes = saved
     torch.cuda.synchronize()
     assert bool((y == 7.0).all())                         # nothing was launched
+
+
+Q4_CASES = [  # (cin, cout, shape): ragged depth / height / width tiles, 1..8 output channels, channel counts off the chunk size
+    (64, 4, (8, 16, 128)), (67, 4, (6, 10, 68)), (25, 1, (9, 17, 64)), (4, 8, (5, 8, 100)), (3, 5, (4, 9, 36)), (9, 7, (13, 7, 132)),
+    (1, 2, (3, 3, 4)), (5, 3, (1, 1, 8)), (137, 8, (4, 8, 64)), (2, 6, (7, 25, 60)),
+]
+
+
+@pytest.fixture
+def q4_forced():
+    from deep_prior_interpolation_amd import _lib
+    L = _lib.load()
+    L.dpi_set_q4(2, 2)
+    yield L
+    L.dpi_set_q4(1, 2)
+
+
+@pytest.mark.parametrize("ck", [2, 4])
+@pytest.mark.parametrize("cin,cout,shape", Q4_CASES)
+def test_conv_q4_kernel_vs_oracle(ops, q4_forced, cin, cout, shape, ck):
+    """csrc/conv_q4_mfma.hip (4x4x1 MFMA, <= 8 output channels) forced onto every shape it can run: forward with bias, and — through
+    a convolution whose INPUT has <= 8 channels — backward-data, against the fp64 oracle; then bit-for-bit agreement of the default
+    dispatch at these small sizes with what it was before (the kernel must not change results where it is not selected)."""
+    q4_forced.dpi_set_q4(2, ck)
+    gen = torch.Generator().manual_seed(cin * 131 + cout)
+    x = torch.randn((1, cin) + shape, generator=gen)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen) * (1.0 / np.sqrt(cin * 27))
+    b = torch.randn(cout, generator=gen)
+    yr = O.conv_nd(x.double(), w.double(), b.double(), 1)
+    y = ops.conv(x.to(DEV), w.to(DEV), b.to(DEV), 1)
+    assert rel(y, yr) < 2e-6
+    # backward-data through the flipped kernel: forward conv cout -> cin has `cout` (<= 8) input channels
+    x2 = torch.randn((1, cout) + shape, generator=gen)
+    w2 = torch.randn((cin, cout, 3, 3, 3), generator=gen) * (1.0 / np.sqrt(cout * 27))
+    xr = x2.double().requires_grad_(True)
+    y2 = O.conv_nd(xr, w2.double(), None, 1)
+    dy = torch.randn(y2.shape, generator=gen)
+    y2.backward(dy.double())
+    d = ops.make_desc(x2.to(DEV), w2.to(DEV), 1)
+    dx = torch.empty(x2.shape, device=DEV)
+    ops.raw_conv_bwd_data(d, dy.to(DEV), w2.to(DEV), dx)
+    assert rel(dx, xr.grad) < 2e-6
+    base = torch.randn(x2.shape, generator=gen).to(DEV)
+    acc = base.clone()
+    ops.raw_conv_bwd_data(d, dy.to(DEV), w2.to(DEV), acc, accumulate=True)
+    assert rel(acc, base + dx) < 1e-6
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(20, 4, (9, 10, 68)), (9, 3, (8, 8, 64)), (6, 8, (5, 9, 40)), (64, 4, (4, 8, 128))])
+def test_conv_q4_chain_stats_and_unaligned_rows(ops, q4_forced, cin, cout, shape):
+    """The same kernel with the producer's BatchNorm + LeakyReLU chain applied on load, the {sum, sum^2} epilogue for the next
+    BatchNorm, and an input whose rows are NOT 16-byte aligned (a view one float into a buffer: dword staging instead of dwordx4)."""
+    import ctypes as C
+    gen = torch.Generator().manual_seed(11 + cin)
+    x = torch.randn((1, cin) + shape, generator=gen)
+    chain = torch.stack([torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen), torch.full((cin,), 0.2),
+                         torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen)], dim=1).contiguous()
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen) * 0.1
+    b = torch.randn(cout, generator=gen)
+    bc = lambda v: v.reshape(1, -1, 1, 1, 1)
+    tx = bc(chain[:, 3]) * O.activation("LeakyReLU", bc(chain[:, 0]) * x + bc(chain[:, 1])) + bc(chain[:, 4])
+    yr = O.conv_nd(tx.double(), w.double(), b.double(), 1)
+    L = q4_forced
+    wg, bg, cg = w.to(DEV), b.to(DEV), chain.to(DEV)
+    for misalign in (0, 1):
+        buf = torch.zeros(x.numel() + 4, device=DEV)
+        xg = buf[misalign:misalign + x.numel()].view(x.shape)
+        xg.copy_(x.to(DEV))
+        assert xg.data_ptr() % 16 == 4 * misalign
+        d = ops.make_desc(xg, wg, 1)
+        nblk = L.dpi_conv_fwd_stat_blocks(C.byref(d))
+        part = torch.zeros(nblk * cout * 2, dtype=torch.float64, device=DEV)
+        y = torch.empty(yr.shape, device=DEV)
+        ops.raw_conv_fwd(d, xg, cg, wg, bg, y, part)
+        assert rel(y, yr) < 2e-6
+        p = part.view(nblk, cout, 2).sum(0).cpu()
+        np.testing.assert_allclose(p[:, 0].numpy(), yr.sum((0, 2, 3, 4)).numpy(), rtol=1e-5, atol=2e-2)
+        np.testing.assert_allclose(p[:, 1].numpy(), (yr ** 2).sum((0, 2, 3, 4)).numpy(), rtol=1e-5)
