@@ -56,6 +56,7 @@ SIGNATURES = {
     "dpi_set_bwd_weight_mfma_min_cout": (None, [_I]),
     "dpi_set_fewco_mfma": (None, [_I]),
     "dpi_set_q4": (None, [_I, _I]),
+    "dpi_set_q4_debug": (None, [_I]),
     "dpi_stat_blocks": (_I, [_I, _Z]),
     "dpi_channel_stats": (_I, [_P, _P, _I, _Z, _P, _P]),
     "dpi_bn_finalize": (_I, [_P, _I, _I, _Z, _P, _P, _F, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P]),

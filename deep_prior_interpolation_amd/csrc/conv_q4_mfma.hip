@@ -107,17 +107,27 @@ __global__ __launch_bounds__(256, 2) void conv_q4_mfma_kernel(QArgs a) {
       }
     }
   };
+  // Two code paths selected by ONE wave-uniform branch.  (Written as `chain && goff >= 0 ? T(x) : x` hipcc first produced an
+  // exec-masked region per element, then — as `chain ? m * T(x) : x` — computed T(x) for every element even without a chain: the
+  // store phase of a chunk took 6.5 k clk instead of a few hundred either way.)
   auto stage_store = [&](const f32x4 (&sr)[CK][G::E], int c0) {
+    if (a.chain == nullptr) {
+#pragma unroll
+      for (int c = 0; c < CK; ++c)
+#pragma unroll
+        for (int e = 0; e < G::E; ++e)
+          if ((e + 1) * 256 <= G::NV4 || loff[e] >= 0) *reinterpret_cast<f32x4*>(lds + c * G::CS + loff[e]) = sr[c][e];
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < CK; ++c) {
       const Chain t = load_chain(a.chain, min(c0 + c, a.Cin - 1));
 #pragma unroll
       for (int e = 0; e < G::E; ++e) {
-        f32x4 v = sr[c][e];
-        if (a.chain && goff[e] >= 0) {
+        const float m = goff[e] >= 0 ? 1.f : 0.f;     // zero padding stays zero through a factor, not a per-lane branch
+        f32x4 v;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = apply_chain(t, v[k]);
-        }
+        for (int k = 0; k < 4; ++k) v[k] = m * apply_chain(t, sr[c][e][k]);
         if ((e + 1) * 256 <= G::NV4 || loff[e] >= 0) *reinterpret_cast<f32x4*>(lds + c * G::CS + loff[e]) = v;
       }
     }
@@ -160,17 +170,6 @@ __global__ __launch_bounds__(256, 2) void conv_q4_mfma_kernel(QArgs a) {
   float wreg[WE];
   load_wt(wreg, 0);
   stage_load(sr, 0);
-  if (a.accumulate) {                                   // gradient fan-in: start from the destination
-#pragma unroll
-    for (int hr = 0; hr < R; ++hr)
-#pragma unroll
-      for (int s = 0; s < NB; ++s)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int co = 4 * s + i, oh = oh0 + hr;
-          if (co < a.Cout && od < Do && oh < Ho && ow < Wo) acc[hr][s][i] = a.y[(size_t)co * V + ((size_t)od * Ho + oh) * Wo + ow];
-        }
-  }
 
   const int xbase = wid * G::DS + 4 + lane;             // centre column of this wave's depth slice (kd = 0), input row 0
   constexpr int NSTEP = CK * 3 * G::IH;                 // (channel, kd, input row) steps of a chunk
@@ -251,7 +250,239 @@ __global__ __launch_bounds__(256, 2) void conv_q4_mfma_kernel(QArgs a) {
 #pragma unroll
       for (int hr = 0; hr < R; ++hr) {
         if (cok && col_ok && oh0 + hr < Ho) {
-          const float v = acc[hr][s][i] + bv;
+          // gradient fan-in (accumulate): the destination is read HERE, not into the accumulators before the channel loop — loads
+          // pending on accumulator registers made hipcc put an s_waitcnt vmcnt(0) in front of the loop's first MFMA, which on every
+          // later chunk waited for the whole halo-tile prefetch issued just before it (measured: 8.7 k instead of 2.8 k clk)
+          const float v = acc[hr][s][i] + bv + (a.accumulate ? yc[hr * Wo] : 0.f);
+          if (!(a.dbg & 8)) yc[hr * Wo] = v;
+          sm += v;
+          sq += (double)v * v;
+        }
+      }
+      if (a.partials && cok) {
+        sm = wave_sum(sm);
+        sq = wave_sum(sq);
+        if (lane == 0) { red[wid][co][0] = sm; red[wid][co][1] = sq; }
+      }
+    }
+  if (a.partials) {
+    __syncthreads();
+    if (tid < 2 * a.Cout) {
+      const int c = tid >> 1, which = tid & 1;
+      a.partials[((size_t)tile_id * a.Cout + c) * 2 + which] = red[0][c][which] + red[1][c][which] + red[2][c][which] + red[3][c][which];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Variant with the 4 input channels of a chunk INTERLEAVED in LDS ([depth][row][column][4 channels]): one ds_read_b128 hands a lane
+// the four channels of its voxel, so an input row costs 3 LDS reads (the kw taps) for 36 NB MFMAs instead of 3 reads for 9 NB.
+// Why it matters (MI355X_MICROARCH.md §LDS, and measured here): a ds_read_b32 reaches its 2-cycle rate only with ~4 waves per SIMD
+// issuing long runs of them; with the 2-3 waves this kernel has, every b32 read cost ~10 clk of the wave's issue time and the
+// compute loop alone ran at 60 % of the MFMA rate.  ds_read_b128 reaches its rate from one wave per SIMD.
+//   staging: a thread loads the same float4 (4 columns) of the 4 channels, transposes the 4x4 block in registers (free) and stores
+//   four 16-byte {c0,c1,c2,c3} positions.  Position (row, col) lives at slot 4 g + (j ^ ((g >> 1) & 3)), g = col >> 2, j = col & 3:
+//   the XOR spreads the 8 lanes of a ds_write_b128 lane group (64 bytes apart otherwise: two banks quads) over all banks.
+//   weights: LDS table [tap][s][i][ci] so that one b128 read gives a lane its row's weights for the 4 channels; held per kd plane.
+template <int R>
+struct QiGeo {
+  static constexpr int TZ = 4, TY = R, TW = 64;
+  static constexpr int ID = TZ + 2, IH = R + 2;
+  static constexpr int NP = 72;                 // positions per row: columns w0 - 4 .. w0 + 67
+  static constexpr int RS = NP * 4, DS = IH * RS, TILE = ID * DS;     // floats
+  static constexpr int NSLOT = ID * IH * 18;    // (row, 4-column group) slots
+  static constexpr int E = (NSLOT + 255) / 256;
+};
+__device__ __forceinline__ int qi_pos(int col) {                     // float offset of logical column `col` inside its LDS row
+  const int g = col >> 2, j = col & 3;
+  return (4 * g + (j ^ ((g >> 1) & 3))) * 4;
+}
+
+template <int R, int NB, bool FLIP, bool AL>
+__global__ __launch_bounds__(256, 2) void conv_q4i_mfma_kernel(QArgs a) {
+  using G = QiGeo<R>;
+  constexpr int TAPS = 27;
+  constexpr int NWT = TAPS * NB * 16;             // weight table of one chunk: [tap][s][i][ci]
+  constexpr int WE = (NWT + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float lds[G::TILE];
+  __shared__ __attribute__((aligned(16))) float wl[NWT];
+  __shared__ double red[4][4 * NB][2];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int ntiles = a.ntd * a.nth * a.ntw;
+  const int tile_id = q4_xcd_tile(blockIdx.x, ntiles);
+  int bt = tile_id;
+  const int tw_i = bt % a.ntw; bt /= a.ntw;
+  const int th_i = bt % a.nth; bt /= a.nth;
+  const int od0 = bt * G::TZ, oh0 = th_i * G::TY, ow0 = tw_i * G::TW;
+  const size_t V = (size_t)a.D * a.H * a.W;
+
+  int goff[G::E], loff[G::E];
+#pragma unroll
+  for (int e = 0; e < G::E; ++e) {
+    const int idx = tid + e * 256;
+    const int q = idx % 18, row = idx / 18;
+    const int hy = row % G::IH, dz = row / G::IH;
+    const int gd = od0 - 1 + dz, gh = oh0 - 1 + hy, gw = ow0 - 4 + 4 * q;
+    const bool ok = idx < G::NSLOT && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw + 4 <= a.W;
+    goff[e] = ok ? (gd * a.H + gh) * a.W + gw : -4;
+    loff[e] = idx < G::NSLOT ? dz * G::DS + hy * G::RS + 16 * q : -1;      // float offset of the slot's 4-position group
+  }
+  const int swz = ((tid % 18) >> 1) & 3;           // XOR of this thread's column groups: q = (tid + 256 e) % 18 — 256 % 18 = 4, see below
+  auto stage_load = [&](f32x4 (&sr)[G::E][4], int c0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ci = min(c0 + c, a.Cin - 1);          // channels past Cin: their weights are zero
+      const __amdgpu_buffer_rsrc_t r = dpi_buffer(a.x + (size_t)ci * V, V * sizeof(float));
+#pragma unroll
+      for (int e = 0; e < G::E; ++e) {
+        if constexpr (AL) sr[e][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, goff[e] * 4, 0, 0));
+        else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) sr[e][c][k] = dpi_buffer_load(r, goff[e] < 0 ? -4 : (goff[e] + k) * 4);
+        }
+      }
+    }
+  };
+  auto stage_store = [&](const f32x4 (&sr)[G::E][4], int c0) {
+    if (a.chain == nullptr) {                         // ONE wave-uniform branch, see the other variant
+#pragma unroll
+      for (int e = 0; e < G::E; ++e) {
+        const int x = (((tid + e * 256) % 18) >> 1) & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                 // column 4 q + j of the slot: {c0, c1, c2, c3}
+          const f32x4 v = (f32x4){sr[e][0][j], sr[e][1][j], sr[e][2][j], sr[e][3][j]};
+          if ((e + 1) * 256 <= G::NSLOT || loff[e] >= 0) *reinterpret_cast<f32x4*>(lds + loff[e] + 4 * (j ^ x)) = v;
+        }
+      }
+      return;
+    }
+    Chain t[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t[c] = load_chain(a.chain, min(c0 + c, a.Cin - 1));
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) {
+      const int x = (((tid + e * 256) % 18) >> 1) & 3;
+      const float m = goff[e] >= 0 ? 1.f : 0.f;       // zero padding stays zero through a factor, not a per-lane branch
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = m * apply_chain(t[c], sr[e][c][j]);
+        if ((e + 1) * 256 <= G::NSLOT || loff[e] >= 0) *reinterpret_cast<f32x4*>(lds + loff[e] + 4 * (j ^ x)) = v;
+      }
+    }
+  };
+  (void)swz;
+  auto wt_index = [&](int t, int c0, bool& ok) {      // t = ((tap * NB + s) * 4 + i) * 4 + c
+    const int c = t & 3, i = (t >> 2) & 3, s = (t >> 4) % NB, tap = (t >> 4) / NB;
+    const int co = 4 * s + i, ci = c0 + c;
+    ok = t < NWT && co < a.Cout && ci < a.Cin;
+    return (ok ? co : 0) * a.w_out_stride + (ok ? ci : 0) * a.w_in_stride + (FLIP ? TAPS - 1 - min(tap, TAPS - 1) : min(tap, TAPS - 1));
+  };
+  auto load_wt = [&](float (&wreg)[WE], int c0) {
+#pragma unroll
+    for (int k = 0; k < WE; ++k) {
+      bool ok;
+      wreg[k] = a.w[wt_index(tid + k * 256, c0, ok)];
+    }
+  };
+  auto store_wt = [&](const float (&wreg)[WE], int c0) {
+#pragma unroll
+    for (int k = 0; k < WE; ++k) {
+      bool ok;
+      wt_index(tid + k * 256, c0, ok);
+      if (tid + k * 256 < NWT) wl[tid + k * 256] = ok ? wreg[k] : 0.f;
+    }
+  };
+
+  const int Do = a.D, Ho = a.H, Wo = a.W;
+  const int od = od0 + wid, ow = ow0 + lane;
+  f32x4 acc[R][NB];
+#pragma unroll
+  for (int hr = 0; hr < R; ++hr)
+#pragma unroll
+    for (int s = 0; s < NB; ++s) acc[hr][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 sr[G::E][4];
+  float wreg[WE];
+  load_wt(wreg, 0);
+  stage_load(sr, 0);
+
+  int xoff[3];                                        // this lane's three kw positions (logical columns 3 + lane + kw) in a row
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) xoff[kw] = wid * G::DS + qi_pos(3 + lane + kw);
+  const f32x4* __restrict__ wl4 = reinterpret_cast<const f32x4*>(wl) + (lane & 3);
+
+  for (int c0 = 0; c0 < a.Cin; c0 += 4) {
+    __syncthreads();
+    if (!(a.dbg & 2) || c0 == 0) stage_store(sr, c0);
+    store_wt(wreg, c0);
+    __syncthreads();
+    auto load_x = [&](f32x4 (&xv)[3], int kd, int ir) {
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) xv[kw] = *reinterpret_cast<const f32x4*>(lds + xoff[kw] + kd * G::DS + ir * G::RS);
+    };
+    auto load_w = [&](f32x4 (&wr)[9][NB], int kd) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int s = 0; s < NB; ++s) wr[t][s] = wl4[((kd * 9 + t) * NB + s) * 4];
+    };
+    f32x4 wr[9][NB], xv[3], xn[3];
+    load_w(wr, 0);
+    load_x(xv, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c0 + 4 < a.Cin) {                               // next chunk's loads fly behind this chunk's MFMAs (after the LDS reads: see above)
+      load_wt(wreg, c0 + 4);
+      if (!(a.dbg & 1)) stage_load(sr, c0 + 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+#pragma unroll
+      for (int ir = 0; ir < G::IH; ++ir) {
+        if (ir + 1 < G::IH) load_x(xn, kd, ir + 1);
+        else if (kd + 1 < 3) load_x(xn, kd + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+              const int hr = ir - kh;
+              if (hr >= 0 && hr < R) {
+#pragma unroll
+                for (int s = 0; s < NB; ++s)
+                  acc[hr][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[kh * 3 + kw][s][c], xv[kw][c], acc[hr][s], 0, 0, 0);
+              }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) xv[kw] = xn[kw];
+      }
+      if (kd + 1 < 3) load_w(wr, kd + 1);
+    }
+  }
+
+  const bool col_ok = od < Do && ow < Wo;
+#pragma unroll
+  for (int s = 0; s < NB; ++s)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = 4 * s + i;
+      const bool cok = co < a.Cout;
+      const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
+      float* __restrict__ yc = a.y + (size_t)(cok ? co : 0) * V + ((size_t)(od < Do ? od : 0) * Ho + oh0) * Wo + ow;
+      double sm = 0.0, sq = 0.0;
+#pragma unroll
+      for (int hr = 0; hr < R; ++hr) {
+        if (cok && col_ok && oh0 + hr < Ho) {
+          // gradient fan-in (accumulate): the destination is read HERE, not into the accumulators before the channel loop — loads
+          // pending on accumulator registers made hipcc put an s_waitcnt vmcnt(0) in front of the loop's first MFMA, which on every
+          // later chunk waited for the whole halo-tile prefetch issued just before it (measured: 8.7 k instead of 2.8 k clk)
+          const float v = acc[hr][s][i] + bv + (a.accumulate ? yc[hr * Wo] : 0.f);
           if (!(a.dbg & 8)) yc[hr * Wo] = v;
           sm += v;
           sq += (double)v * v;
@@ -273,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void conv_q4_mfma_kernel(QArgs a) {
 }
 
 static int g_q4 = 1;          // dpi_set_q4: 0 off, 1 where it pays (below), 2 every shape it can run (tests)
-static int g_q4_ck = 2;
+static int g_q4_ck = 0;        // 0: by shape (q4_launch), 2 / 4: force the planar / the channel-interleaved variant
 static int g_q4_dbg = 0;
 
 }  // namespace
@@ -281,7 +512,7 @@ static int g_q4_dbg = 0;
 extern "C" void dpi_set_q4_debug(int flags) { g_q4_dbg = flags; }
 extern "C" void dpi_set_q4(int on, int ck) {
   if (on >= 0) g_q4 = on;
-  if (ck == 2 || ck == 4) g_q4_ck = ck;
+  if (ck == 0 || ck == 2 || ck == 4) g_q4_ck = ck;
 }
 
 // Where it applies: 3-D 3x3x3 stride 1 with <= 8 output channels (flip: the convolution's INPUT channels are the outputs of the
@@ -304,17 +535,18 @@ int dpi_conv_q4_tiles(const dpi_conv_desc* d, int* ntd, int* nth, int* ntw) {
 
 template <int NB, bool FLIP>
 static void q4_launch(const QArgs& a, int ntiles, bool aligned, hipStream_t st) {
-  if constexpr (NB == 1) {          // (CK = 4 with two row blocks does not fit the register file)
-    if (g_q4_ck == 4) {
-      if (aligned) conv_q4_mfma_kernel<8, NB, 4, FLIP, true><<<ntiles, 256, (size_t)(g_q4_dbg >> 8) * 1024, st>>>(a);
-      else conv_q4_mfma_kernel<8, NB, 4, FLIP, false><<<ntiles, 256, (size_t)(g_q4_dbg >> 8) * 1024, st>>>(a);
+  const size_t extra = (size_t)((g_q4_dbg >> 8) & 255) * 1024;
+  if constexpr (NB == 1) {          // (two row blocks: the interleaved variant spills — 72 weight + 64 accumulator + 80 staging registers)
+    // channel-interleaved LDS tile, ds_read_b128 operands: 5 % faster on the long channel loops (64 -> 4: 0.835 -> 0.787 ms, 67 -> 4:
+    // 0.781 -> 0.753), equal on the short ones
+    if (g_q4_ck == 4 || (g_q4_ck == 0 && a.Cin >= 16)) {
+      if (aligned) conv_q4i_mfma_kernel<8, NB, FLIP, true><<<ntiles, 256, extra, st>>>(a);
+      else conv_q4i_mfma_kernel<8, NB, FLIP, false><<<ntiles, 256, extra, st>>>(a);
       return;
     }
   }
-  {
-    if (aligned) conv_q4_mfma_kernel<8, NB, 2, FLIP, true><<<ntiles, 256, (size_t)(g_q4_dbg >> 8) * 1024, st>>>(a);
-    else conv_q4_mfma_kernel<8, NB, 2, FLIP, false><<<ntiles, 256, (size_t)(g_q4_dbg >> 8) * 1024, st>>>(a);
-  }
+  if (aligned) conv_q4_mfma_kernel<8, NB, 2, FLIP, true><<<ntiles, 256, extra, st>>>(a);
+  else conv_q4_mfma_kernel<8, NB, 2, FLIP, false><<<ntiles, 256, extra, st>>>(a);
 }
 
 int dpi_conv_q4_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,

@@ -107,8 +107,12 @@ void dpi_set_bwd_weight_mfma_min_cout(int n);
 void dpi_set_fewco_mfma(int on);
 /* Tuning / test hook of the 4x4x1-MFMA kernel for 3x3x3 stride-1 convolutions with <= 8 output channels (csrc/conv_q4_mfma.hip):
  * on = 0 routes those shapes back to the 16x16x4 kernels, 1 (default) uses it where it pays, 2 wherever it can run (tests); < 0 keeps
- * the setting; ck in {2, 4} = input channels per chunk (other values keep the setting). */
+ * the setting; ck = 2 / 4 forces the planar (2 input channels per chunk, ds_read_b32 operands) / the channel-interleaved variant
+ * (4 channels per chunk, ds_read_b128 operands), 0 picks by shape (default); other values keep the setting. */
 void dpi_set_q4(int on, int ck);
+/* ... its phase-skipping switches (timing experiments, wrong results): bit 0 no input loads after the first chunk, bit 1 no LDS stores
+ * after it, bit 2 no MFMAs, bit 3 no output stores, bit 5 no barriers; bits 8-15 = KiB of extra dynamic LDS (occupancy experiments). */
+void dpi_set_q4_debug(int flags);
 
 /* ---------------------------------------------------------------- BatchNorm / activations -------
  * Replaces nn.BatchNorm3d/2d in training mode (base.py:164,214; mulresunet.py:80-81,104,225) and

@@ -735,7 +735,7 @@ def q4_forced():
     L = _lib.load()
     L.dpi_set_q4(2, 2)
     yield L
-    L.dpi_set_q4(1, 2)
+    L.dpi_set_q4(1, 0)
 
 
 @pytest.mark.parametrize("ck", [2, 4])

@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--bw-xcd", type=int, default=-1, help="backward-weight plan: XCD-aware workgroup order 0/1")
     ap.add_argument("--q4", type=int, default=-1, help="4x4x1-MFMA few-output-channel kernel: 0 off, 1 where it pays, 2 forced (dpi_set_q4)")
     ap.add_argument("--q4-debug", type=int, default=0, help="phase-skipping bits of the q4 kernel (timing experiments, wrong results)")
-    ap.add_argument("--q4-ck", type=int, default=0, help="... its input channels per chunk (2 or 4)")
+    ap.add_argument("--q4-ck", type=int, default=-1, help="... its input channels per chunk (2 or 4)")
     a = ap.parse_args()
     L = _lib.load()
     if a.mfma_min_cout is not None:
@@ -48,7 +48,6 @@ def main():
     L.dpi_set_bw_tuning(a.bw_want, a.bw_xcd)
     L.dpi_set_q4(a.q4, a.q4_ck)
     if a.q4_debug:
-        L.dpi_set_q4_debug.argtypes = [C.c_int]
         L.dpi_set_q4_debug(a.q4_debug)
     ops.set_precision(a.precision)
     if a.bf16_debug:
