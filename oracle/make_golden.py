@@ -310,6 +310,22 @@ def gen_unet():
     save("unet", out)
 
 
+def gen_skip2d():
+    """Reference 2-D Skip class (architectures/skip.py:5-48) driven directly — `get_net` never returns it, so no Interpolator run
+    reaches it; forward + backward of a tiny hourglass (two scales, odd width -> Concat crop) in both up-sampling modes."""
+    from architectures.skip import Skip
+    g = torch.Generator().manual_seed(123)
+    out = {}
+    for mode, shape in (("nearest", (1, 5, 16, 20)), ("bilinear", (1, 5, 18, 14))):
+        m = Skip(num_input_channels=5, num_output_channels=2, num_channels_down=[4, 6], num_channels_up=[4, 6], num_channels_skip=[2, 3],
+                 upsample_mode=mode, act_fun="LeakyReLU")
+        randomize(m, g)
+        d = {"state": sd_np(m), "keys": np.array(json.dumps([[k, list(v.shape)] for k, v in m.state_dict().items()]))}
+        d.update(fwd_bwd(m, torch.randn(shape, generator=g), g))
+        out[mode] = d
+    save("skip2d", out)
+
+
 def gen_structure():
     """state_dict key/shape tables and parameter counts of the full-size nets."""
     import architectures
@@ -613,7 +629,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref_shim.install()
     todo = {"ops": gen_ops, "blocks": gen_blocks, "nets": gen_nets, "structure": gen_structure, "host": gen_host,
-            "unet": gen_unet, "acts": gen_acts, "operators": gen_operators, "lines": gen_lines, "checkpoint": gen_checkpoint}
+            "unet": gen_unet, "skip2d": gen_skip2d, "acts": gen_acts, "operators": gen_operators, "lines": gen_lines, "checkpoint": gen_checkpoint}
     for k, fn in todo.items():
         if a.only is None or k in a.only:
             fn()

@@ -218,6 +218,37 @@ def test_unet_golden(golden, mode):
             assert rel(p.grad, ref) < 5e-4, k
 
 
+@pytest.mark.parametrize("mode", ["nearest", "bilinear"])
+def test_skip2d_golden(golden, mode):
+    """The 2-D `Skip` hourglass (reference architectures/skip.py:5-48; `get_net` never returns it upstream, so it is driven as a
+    class on both sides): forward, input gradient and every parameter gradient against the reference's own on the same weights,
+    two scales, odd sizes through the Concat centre-crop, both up-sampling modes."""
+    from deep_prior_interpolation_amd.architectures.skip import Skip
+    g = golden("skip2d")[mode]
+    m = Skip(num_input_channels=5, num_output_channels=2, num_channels_down=[4, 6], num_channels_up=[4, 6], num_channels_skip=[2, 3],
+             upsample_mode=mode, act_fun="LeakyReLU")
+    keys = jstr(g["keys"])
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == keys
+    m = _load_sd(m, g["state"])
+    x = G(g["x"], True)
+    y = m(x)
+    assert rel(y, g["y"]) < 1e-4
+    y.backward(G(g["dy"]))
+    assert rel(x.grad, g["dx"]) < 5e-4
+    worst = 0.0
+    for k, p in m.named_parameters():
+        ref = g["grads"][k]
+        scale = float(np.abs(ref).max())
+        if p.grad is None:                                     # conv bias feeding a BatchNorm: analytically zero, reported as None
+            assert scale < 1e-3 * max(float(np.abs(g["grads"][k[:-4] + "weight"]).max()), 1e-6), k
+            continue
+        if k.endswith("bias") and scale < 1e-4 * float(np.abs(g["grads"][k[:-4] + "weight"]).max()):
+            continue                                           # rounding-noise gradient on the reference side too
+        worst = max(worst, rel(p.grad, ref))
+        assert rel(p.grad, ref) < 2e-3, k
+    print("skip2d %s: worst parameter-gradient error %.2e" % (mode, worst))
+
+
 def test_unet_leaf_ops_golden(golden):
     from deep_prior_interpolation_amd import ops
     g = golden("unet")

@@ -263,3 +263,16 @@ def test_hyperbolic3d_stand_in_statistics():
     assert np.array_equal(u.hyperbolic_volume((48, 32, 32), seed=3), u.hyperbolic_volume((48, 32, 32), seed=3))
     old = u.sparse_hyperbolic_volume((256, 128, 128), seed=0)
     assert u.coarse_std(old, u.random_trace_mask((256, 128, 128), 0.66, seed=1)) < 2.5
+
+
+def test_skip2d_structure(golden):
+    """2-D `Skip` (reference architectures/skip.py:5-48): state_dict keys, order and shapes equal the reference's, so checkpoints of
+    either implementation load in the other (the class is unreachable through `get_net` on both sides)."""
+    from deep_prior_interpolation_amd.architectures.skip import Skip
+    for mode in ("nearest", "bilinear"):
+        g = golden("skip2d")[mode]
+        m = Skip(num_input_channels=5, num_output_channels=2, num_channels_down=[4, 6], num_channels_up=[4, 6], num_channels_skip=[2, 3],
+                 upsample_mode=mode, act_fun="LeakyReLU")
+        assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == jstr(g["keys"])
+    with pytest.raises(NotImplementedError):
+        Skip(pad="reflection")

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""gpurun_out/<prefix>_hbm_iteration_{FETCH,WRITE}_SIZE.txt (+ _family_*) -> the JSON bench.py reads for `roofline.traffic` /
+`roofline.measured_over_algorithmic` (profiles/r03_traffic.json).  Units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB (1024 B);
+on gfx950 FETCH_SIZE counts 64-byte units as 32 (MI355X_MICROARCH.md, HBM / rocprofv3 section; confirmed by the round-1 calibration
+on kernels with known byte counts, profiles/r01_traffic_dominant_conv.json): reads = FETCH_SIZE x 2, writes = WRITE_SIZE x 1."""
+import json
+import re
+import sys
+
+pre, iters = sys.argv[1], int(sys.argv[2])
+
+
+def totals(path):
+    per_iter, kernels = None, {}
+    for line in open(path):
+        m = re.match(r"\w+: total ([\d.e+]+) over all dispatches = ([\d.e+]+) per iteration", line)
+        if m:
+            per_iter = float(m.group(2))
+            continue
+        m = re.match(r"\s+([\d.e+]+) per iteration\s+[\d.]+ %\s+(.*)", line)
+        if m:
+            kernels[m.group(2).strip()] = float(m.group(1))
+    return per_iter, kernels
+
+
+def family(path):
+    """per-launch averages of the 3x3x3 stride-1 backward-weight kernels (conv_bwd_weight_mfma_kernel<3, 1, 8, 2, *>, smallco)."""
+    rows, key = [], None
+    for line in open(path):
+        if not line.startswith(" "):
+            key = line.strip()
+        else:
+            m = re.match(r"\s+(\w+)\s+n=(\d+) avg=([\d.e+]+)", line)
+            if m and key and (re.search(r"conv_bwd_weight_mfma_kernel<3, 1, 8, 2", key) or "smallco" in key):
+                rows.append((key, int(m.group(2)), float(m.group(3))))
+    return rows
+
+
+f_it, f_k = totals(pre + "_hbm_iteration_FETCH_SIZE.txt")
+w_it, w_k = totals(pre + "_hbm_iteration_WRITE_SIZE.txt")
+fam_f, fam_w = family(pre + "_family_FETCH_SIZE.txt"), family(pre + "_family_WRITE_SIZE.txt")
+n_launch = sum(n for _, n, _ in fam_f)
+fam_read = sum(n * v for _, n, v in fam_f) * 1024.0 * 2.0
+fam_write = sum(n * v for _, n, v in fam_w) * 1024.0
+read_b, write_b = f_it * 1024.0 * 2.0, w_it * 1024.0
+top = sorted(f_k.items(), key=lambda kv: -kv[1])[:8]
+out = {
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
+              "--no-other-modes --no-c3-extra` (tools/profile_r03.sh pmc_iter), weight-gradient side stream off, %d iterations per pass; "
+              "units KB = 1024 B; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950" % iters,
+    "precision": "fp32",
+    "whole_iteration": {"FETCH_SIZE_KB_per_iteration": f_it, "WRITE_SIZE_KB_per_iteration": w_it, "read_bytes": read_b, "write_bytes": write_b,
+                        "hbm_bytes_per_iteration": read_b + write_b, "algorithmic_bytes_per_iteration": 39.18e9,
+                        "measured_over_algorithmic": round((read_b + write_b) / 39.18e9, 3),
+                        "top_readers_KB_raw_per_iteration": {k: v for k, v in top}},
+    "dominant_family": {"family": "conv_bwd_weight k3 s1",
+                        "kernels": "conv_bwd_weight_mfma_kernel<3, 1, 8, 2, *> (both orientations, tail launches) and conv_bwd_weight_smallco_kernel",
+                        "launches_counted": n_launch, "launches_per_iteration": n_launch / float(iters),
+                        "read_bytes_per_iteration": fam_read / iters, "write_bytes_per_iteration": fam_write / iters,
+                        "hbm_bytes_per_launch_mean": (fam_read + fam_write) / max(n_launch, 1),
+                        "per_grid_KB_raw": {"FETCH_SIZE": [[k, n, v] for k, n, v in fam_f], "WRITE_SIZE": [[k, n, v] for k, n, v in fam_w]}},
+}
+print(json.dumps(out, indent=1))
