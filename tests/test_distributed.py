@@ -38,10 +38,20 @@ def _worker(rank, world, port, shape, dim, stride, gain, outdir, dynamic=False):
     queue, fn = None, _fake_optimise
     if dynamic:
         import time
+        from torch.distributed import distributed_c10d
         queue = P.PatchQueue.for_process_group(len(patches))
+        store = distributed_c10d._get_default_store()
+        state = {"held": False}
 
-        def fn(i, patch):                      # rank 0 is the slow rank: the shared counter must route most patches to rank 1
-            time.sleep(0.05 if rank == 0 else 0.002)
+        def fn(i, patch):
+            # rank 0 is the slow rank, made slow by an explicit hand-shake instead of a sleep ratio (no wall-clock assumption): it
+            # holds its FIRST patch until rank 1 has finished 30 of the 48 — the shared counter must have routed those to rank 1
+            if rank == 1:
+                store.add("dpi/test/rank1_done", 1)
+            elif not state["held"]:
+                state["held"] = True
+                while int(store.add("dpi/test/rank1_done", 0)) < 30:
+                    time.sleep(0.001)
             return _fake_optimise(i, patch)
     rec, mine = P.run_patches(list(patches), origins, shape, dim, stride, gain, fn, rank, world, queue=queue)
     np.save(os.path.join(outdir, "rec_%d.npy" % rank), rec)
@@ -81,7 +91,7 @@ def test_two_rank_shared_queue_balances_uneven_ranks(tmp_path):
     np.testing.assert_array_equal(r0, r1)
     m0, m1 = list(np.load(tmp_path / "mine_0.npy")), list(np.load(tmp_path / "mine_1.npy"))
     assert sorted(m0 + m1) == list(range(len(pa))) and not set(m0) & set(m1)
-    assert len(m1) > 2 * len(m0) > 0, (len(m0), len(m1))
+    assert len(pa) == 48 and len(m1) >= 30 and len(m0) >= 1, (len(m0), len(m1))
 
 
 def test_patch_queue_local_and_static():

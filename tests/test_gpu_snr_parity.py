@@ -24,7 +24,8 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "snr_spread.npz")
 N_SEEDS_HIP = int(os.environ.get("DPI_SNR_SEEDS", "24"))   # 48 (all the reference's seeds) is the run recorded in DESIGN.md §4: +0.22 dB, 2 s.e. 0.34;
                                                             # the default keeps the GPU suite near six minutes (24 seeds: +0.31 dB, 2 s.e. 0.40)
-ALARM = 3.0          # standard errors, see the module docstring
+ALARM = 3.0          # standard errors, see the module docstring.  FROZEN since round 2: bars below are not re-tuned
+                     # to observed values; a failure means either a real regression or a < 0.3 % statistical event.
 
 
 def _escape(snr, level=1.0):
@@ -152,26 +153,69 @@ def test_plateau_length_grows_with_the_volume_as_in_the_reference():
         assert 0.65 * min(mine) <= r <= 1.35 * max(mine), (r, mine)
 
 
+def test_mid_size_snr_matches_the_reference_at_big_tile_size():
+    """configs[1]'s SNR statement at a size whose full-resolution level runs the SAME kernel variants as the bench patch (the
+    4x8x32 / 4x4x32 MFMA tiles and the 4x4x1 few-channel kernel need >= 512 tiles: 128x64x64 is the smallest such volume), on the
+    notebook-like stand-in (`u.hyperbolic_volume`, std of the coarse data 4.47 as in proof_of_concept_3D.ipynb:355,362).
+    tests/golden/snr_mid_128x64x64.npz: the reference's own Interpolator (oracle/make_snr_spread.py --mid, imported from
+    /root/reference; 2 CPU threads per seed, ~2.6 h per seed), seeds 0..2, 1200 Adam iterations, loss / SNR / PCORR history.
+    Here: the HIP path on the same volume, mask and hyper-parameters, seeds 0..5 (bit-identical initial weights for 0..2, its own
+    Philox noise).  Bars fixed a priori from the (48,32,32) protocol, where the reference's seed-to-seed standard deviation of
+    SNR(out_best) is 0.88 dB: mean trajectory within max(3 s.e., 1 dB) of the reference's at every checkpoint, mean SNR(out_best)
+    within 1 dB, and no HIP run outside the reference's range widened by 1.5 dB."""
+    import hashlib
+    from deep_prior_interpolation_amd import utils as u
+    z = np.load(os.path.join(os.path.dirname(GOLD), "snr_mid_128x64x64.npz"))
+    shape = tuple(int(n) for n in z["shape"])
+    assert shape == (128, 64, 64)
+    vol = u.hyperbolic_volume(shape, seed=0)
+    mask = u.random_trace_mask(shape, 0.66, seed=1)
+    assert hashlib.sha1(vol.astype(np.float32).tobytes()).hexdigest() == str(z["volume_sha1"])
+    assert hashlib.sha1(mask.astype(np.uint8).tobytes()).hexdigest() == str(z["mask_sha1"])
+    assert 3.9 <= u.coarse_std(vol, mask) <= 5.2 and abs(u.coarse_std(vol, mask) - float(z["std"][0])) < 1e-3
+    ref = z["snr"].astype(np.float64)                       # [seed][iteration], common length of the recorded seeds
+    n_it = ref.shape[1]
+    assert ref.shape[0] >= 3 and n_it >= 600
+    got = [_run_seed(s, vol, mask, n_it) for s in range(6)]
+    mine = np.stack([g[2] for g in got])
+    print("reference iterations recorded per seed: %s (done: %s)" % (z["iterations"], z["done"]))
+    for it in [i for i in (100, 220, 300, 500, 800, 1199) if i < n_it]:
+        a, b = mine[:, it - 10:it + 1].mean(axis=1), ref[:, it - 10:it + 1].mean(axis=1)
+        se = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
+        print("iteration %4d: SNR HIP %.2f dB (n=%d), reference %.2f dB (n=%d), s.e. of the difference %.2f" % (it, a.mean(), len(a), b.mean(), len(b), se))
+        assert abs(a.mean() - b.mean()) <= max(3.0 * se, 1.0), (it, a.mean(), b.mean(), se)
+    if bool(np.all(z["done"] == 1)):                        # SNR(out_best) is the end-of-run quantity: compared once every seed has finished
+        rb = z["snr_out_best"].astype(np.float64)
+        hb = np.array([g[0] for g in got])
+        print("SNR(out_best): HIP %.2f +- %.2f dB (n=%d), reference %.2f +- %.2f dB (n=%d): difference %+.2f dB"
+              % (hb.mean(), hb.std(ddof=1), len(hb), rb.mean(), rb.std(ddof=1), len(rb), hb.mean() - rb.mean()))
+        assert abs(hb.mean() - rb.mean()) <= 1.0
+        assert hb.min() >= rb.min() - 1.5 and hb.max() <= rb.max() + 1.5
+    # both sides leave 0 dB within the first ~100 iterations on this cube (the sparse round-1/2 cube: 335-435 at 96x64x64)
+    assert max(_escape(s) for s in mine) < 200 and max(_escape(s) for s in ref) < 200
+
+
 def test_full_length_run_at_bench_geometry():
     """One complete optimisation as the reference's notebook runs it (proof_of_concept_3D.ipynb:354-358, main.py:195-220): patch
-    256x128x128, default net, 3000 Adam iterations, on the synthetic stand-in (32 hyperbolic events) with 66 % missing traces.
-    ~2 minutes of GPU.  At this volume the all-zero plateau (previous test) lasts 1400-1500 iterations on this cube (1700-2700
-    on the 5-event cube, profiles/r02_full_run_256x128x128.json and DESIGN.md §4), so the run spends half its iterations at 0 dB
-    and the rest climbing: committed runs reach SNR(out_best) 8.1 / 8.7 dB (seeds 0 / 1, profiles/r02_full_run_dense*.json),
-    still rising.  Kernels are deterministic, but any kernel change re-rolls the chaotic plateau length (1700 vs 2750 iterations on
-    the 5-event cube between two builds), hence the loose bars: off the plateau before iteration 2800, SNR(out_best) > 2 dB."""
+    256x128x128, default net, 3000 Adam iterations, on the notebook-like stand-in with 66 % missing traces.  ~2 minutes of GPU.
+    The notebook's curve (cell 22, on the absent hyperbolic3d data): 0 dB until iteration ~220, ~14 dB at 500, 16.69 dB at 3000.
+    Bars (fixed a priori from that curve and from the reference's mid-size recording, previous test: ~21 dB by iteration 1200):
+    off 0 dB before iteration 600, SNR(out_best) >= 18 dB, at least 14 dB by iteration 500.  Committed run of this build:
+    profiles/r03/full_run_256x128x128_seed0.json (leaves 0 dB at iteration 50, 18.5 dB at 500, SNR(out_best) 24.7 dB)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = os.path.join(root, "gpurun_out", "full_run_test.json")
+    out = os.path.join("/tmp", "dpi_full_run_test.json")
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "full_run.py"), "--out", out], timeout=900)
     with open(out) as fp:
         r = json.load(fp)
     print("full run: %d iterations in %.1f s (%.2f it/s), SNR(out_best) %.2f dB, min loss %.4f at %d, last-50 SNR %.2f +- %.2f dB"
           % (r["epochs"], r["seconds"], r["it_per_s"], r["snr_out_best_db"], r["loss_min"], r["argmin"], r["snr_last50_mean"], r["snr_last50_std"]))
     assert r["epochs"] == 3000 and r["finite"]
-    assert 0 < _escape(r["snr_db"]) * r["trajectory_every"] < 2800
-    assert r["snr_out_best_db"] > 2.0
-    assert r["loss"][-1] < 0.9 * r["loss"][0]
-    assert r["it_per_s"] > 20.0
+    assert 3.9 <= r["std_masked"] <= 5.2
+    every = r["trajectory_every"]
+    assert 0 < _escape(r["snr_db"]) * every < 600
+    assert r["snr_db"][500 // every] >= 14.0
+    assert r["snr_out_best_db"] >= 18.0
+    assert r["loss"][-1] < 0.5 * r["loss"][0]
