@@ -503,6 +503,10 @@ __global__ __launch_bounds__(256, 2) void conv_q4i_mfma_kernel(QArgs a) {
   }
 }
 
+// (Built, measured and removed in round 3: a "wide" variant for <= 4 INPUT channels and many outputs — backward-data of 67 -> 4 and
+//  25 -> 1 — that stages the 4-channel tile once per workgroup, keeps all weights in LDS and walks the output channels in passes of 8.
+//  31 parity cases green; 67 -> 4 backward-data 1.10 ms against 0.80 ms on the 16x16x4 kernel (25 -> 1: 0.44 vs 0.30): one workgroup
+//  per CU and a per-pass prologue / epilogue every 1728 MFMAs cost more than the five-fold tile staging it saved.)
 static int g_q4 = 1;          // dpi_set_q4: 0 off, 1 where it pays (below), 2 every shape it can run (tests)
 static int g_q4_ck = 0;        // 0: by shape (q4_launch), 2 / 4: force the planar / the channel-interleaved variant
 static int g_q4_dbg = 0;

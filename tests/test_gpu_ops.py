@@ -726,6 +726,8 @@ def test_stale_descriptor_layouts_are_rejected():
 Q4_CASES = [  # (cin, cout, shape): ragged depth / height / width tiles, 1..8 output channels, channel counts off the chunk size
     (64, 4, (8, 16, 128)), (67, 4, (6, 10, 68)), (25, 1, (9, 17, 64)), (4, 8, (5, 8, 100)), (3, 5, (4, 9, 36)), (9, 7, (13, 7, 132)),
     (1, 2, (3, 3, 4)), (5, 3, (1, 1, 8)), (137, 8, (4, 8, 64)), (2, 6, (7, 25, 60)),
+    # few input channels, many outputs (not this kernel's shapes: the dispatcher must route them elsewhere, also when it is forced)
+    (3, 20, (5, 9, 36)), (4, 67, (6, 10, 68)), (1, 9, (4, 4, 8)),
 ]
 
 
@@ -767,9 +769,22 @@ def test_conv_q4_kernel_vs_oracle(ops, q4_forced, cin, cout, shape, ck):
     acc = base.clone()
     ops.raw_conv_bwd_data(d, dy.to(DEV), w2.to(DEV), acc, accumulate=True)
     assert rel(acc, base + dx) < 1e-6
+    # backward-data of the forward convolution itself: dy has `cout` channels, dx `cin`
+    xr = x.double().requires_grad_(True)
+    y3 = O.conv_nd(xr, w.double(), None, 1)
+    dy3 = torch.randn(y3.shape, generator=gen)
+    y3.backward(dy3.double())
+    d3 = ops.make_desc(x.to(DEV), w.to(DEV), 1)
+    dx3 = torch.empty(x.shape, device=DEV)
+    ops.raw_conv_bwd_data(d3, dy3.to(DEV), w.to(DEV), dx3)
+    assert rel(dx3, xr.grad) < 2e-6
+    base3 = torch.randn(x.shape, generator=gen).to(DEV)
+    acc3 = base3.clone()
+    ops.raw_conv_bwd_data(d3, dy3.to(DEV), w.to(DEV), acc3, accumulate=True)
+    assert rel(acc3, base3 + dx3) < 1e-6
 
 
-@pytest.mark.parametrize("cin,cout,shape", [(20, 4, (9, 10, 68)), (9, 3, (8, 8, 64)), (6, 8, (5, 9, 40)), (64, 4, (4, 8, 128))])
+@pytest.mark.parametrize("cin,cout,shape", [(20, 4, (9, 10, 68)), (9, 3, (8, 8, 64)), (6, 8, (5, 9, 40)), (64, 4, (4, 8, 128)), (4, 19, (5, 9, 72))])
 def test_conv_q4_chain_stats_and_unaligned_rows(ops, q4_forced, cin, cout, shape):
     """The same kernel with the producer's BatchNorm + LeakyReLU chain applied on load, the {sum, sum^2} epilogue for the next
     BatchNorm, and an input whose rows are NOT 16-byte aligned (a view one float into a buffer: dword staging instead of dwordx4)."""
