@@ -992,6 +992,8 @@ extern "C" void dpi_set_bw_tuning(int want_workgroups, int xcd_order) {
   if (want_workgroups > 0) g_bw_want = want_workgroups;
   if (xcd_order >= 0) g_bw_xcd_order = xcd_order;
 }
+// occupancy experiments: DPI_BW_EXTRA_LDS=<KiB> of unused dynamic LDS per workgroup (44 KB static: 3 workgroups per CU by default)
+static size_t bw_extra_lds() { static const size_t v = getenv("DPI_BW_EXTRA_LDS") ? (size_t)atoi(getenv("DPI_BW_EXTRA_LDS")) * 1024 : 0; return v; }
 struct MfmaBwPlan { int nchunks, tiles_per_chunk, ntiles, ntd, nth, ntw, nr, nh; };
 static MfmaBwPlan mfma_bw_plan(const dpi_conv_desc* d, bool swap = false) {
   MfmaBwPlan p{};
@@ -1041,13 +1043,13 @@ int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const f
     // staged channel count 4m + 1: full groups in one launch, the one-channel group in a second, column-trimmed one
     dim3 gmain(grid.x, grid.y - 1, grid.z), gtail(grid.x, 1, grid.z);
     dim3 gm = xcd_grid(gmain);
-    conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<gm, 256, 0, st>>>(a);
+    conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<gm, 256, bw_extra_lds(), st>>>(a);
     a.y0 = (int)grid.y - 1;
     dim3 gt = xcd_grid(gtail);
     conv_bwd_weight_mfma_kernel<3, 1, 8, 2, 1><<<gt, 256, 0, st>>>(a);
   } else if (d->stride == 1) {
     dim3 g = xcd_grid(grid);
-    if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<g, 256, 0, st>>>(a);
+    if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<g, 256, bw_extra_lds(), st>>>(a);
     else conv_bwd_weight_mfma_kernel<1, 1, 8, 2><<<g, 256, 0, st>>>(a);
   } else if (p.nh == 2) {
     dim3 g = xcd_grid(grid);
