@@ -247,13 +247,22 @@ __global__ __launch_bounds__(256, 2) void conv_q4_mfma_kernel(QArgs a) {
       const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
       float* __restrict__ yc = a.y + (size_t)(cok ? co : 0) * V + ((size_t)(od < Do ? od : 0) * Ho + oh0) * Wo + ow;
       double sm = 0.0, sq = 0.0;
+      // gradient fan-in (accumulate): the destination is read HERE, not into the accumulators before the channel loop — loads
+      // pending on accumulator registers made hipcc put an s_waitcnt vmcnt(0) in front of the loop's first MFMA, which on every
+      // later chunk waited for the whole halo-tile prefetch issued just before it (measured: 8.7 k instead of 2.8 k clk).  All R
+      // loads of a channel are issued together (one wave-uniform branch): read-add-store per element serialised them (2.4 x slower)
+      float old[R];
+      if (a.accumulate) {
+#pragma unroll
+        for (int hr = 0; hr < R; ++hr) old[hr] = (cok && col_ok && oh0 + hr < Ho) ? yc[hr * Wo] : 0.f;
+      } else {
+#pragma unroll
+        for (int hr = 0; hr < R; ++hr) old[hr] = 0.f;
+      }
 #pragma unroll
       for (int hr = 0; hr < R; ++hr) {
         if (cok && col_ok && oh0 + hr < Ho) {
-          // gradient fan-in (accumulate): the destination is read HERE, not into the accumulators before the channel loop — loads
-          // pending on accumulator registers made hipcc put an s_waitcnt vmcnt(0) in front of the loop's first MFMA, which on every
-          // later chunk waited for the whole halo-tile prefetch issued just before it (measured: 8.7 k instead of 2.8 k clk)
-          const float v = acc[hr][s][i] + bv + (a.accumulate ? yc[hr * Wo] : 0.f);
+          const float v = acc[hr][s][i] + bv + old[hr];
           if (!(a.dbg & 8)) yc[hr * Wo] = v;
           sm += v;
           sq += (double)v * v;
@@ -476,13 +485,22 @@ __global__ __launch_bounds__(256, 2) void conv_q4i_mfma_kernel(QArgs a) {
       const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
       float* __restrict__ yc = a.y + (size_t)(cok ? co : 0) * V + ((size_t)(od < Do ? od : 0) * Ho + oh0) * Wo + ow;
       double sm = 0.0, sq = 0.0;
+      // gradient fan-in (accumulate): the destination is read HERE, not into the accumulators before the channel loop — loads
+      // pending on accumulator registers made hipcc put an s_waitcnt vmcnt(0) in front of the loop's first MFMA, which on every
+      // later chunk waited for the whole halo-tile prefetch issued just before it (measured: 8.7 k instead of 2.8 k clk).  All R
+      // loads of a channel are issued together (one wave-uniform branch): read-add-store per element serialised them (2.4 x slower)
+      float old[R];
+      if (a.accumulate) {
+#pragma unroll
+        for (int hr = 0; hr < R; ++hr) old[hr] = (cok && col_ok && oh0 + hr < Ho) ? yc[hr * Wo] : 0.f;
+      } else {
+#pragma unroll
+        for (int hr = 0; hr < R; ++hr) old[hr] = 0.f;
+      }
 #pragma unroll
       for (int hr = 0; hr < R; ++hr) {
         if (cok && col_ok && oh0 + hr < Ho) {
-          // gradient fan-in (accumulate): the destination is read HERE, not into the accumulators before the channel loop — loads
-          // pending on accumulator registers made hipcc put an s_waitcnt vmcnt(0) in front of the loop's first MFMA, which on every
-          // later chunk waited for the whole halo-tile prefetch issued just before it (measured: 8.7 k instead of 2.8 k clk)
-          const float v = acc[hr][s][i] + bv + (a.accumulate ? yc[hr * Wo] : 0.f);
+          const float v = acc[hr][s][i] + bv + old[hr];
           if (!(a.dbg & 8)) yc[hr * Wo] = v;
           sm += v;
           sq += (double)v * v;

@@ -109,16 +109,23 @@ __device__ __forceinline__ void philox4(uint64_t ctr, uint64_t stream_id, uint64
 __global__ __launch_bounds__(256) void noise_kernel(const float* __restrict__ zin, size_t n, float mean, float std, uint64_t seed,
                                                     const uint64_t* __restrict__ step_ptr, uint64_t stream_id,
                                                     float* __restrict__ out) {
+  typedef float nz_f32x4 __attribute__((ext_vector_type(4)));
   const uint64_t sid = step_ptr ? *step_ptr : stream_id;
   const bool vec = (n & 3) == 0;
+  const bool nt = n >= ((size_t)32 << 20);          // streaming tensors beyond the Infinity Cache: non-temporal accesses (elementwise.hip)
   for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q * 4 < n; q += (size_t)gridDim.x * 256) {
     float z[4];
     philox4(q, sid, seed, z);
     const size_t i = q * 4;
     if (vec) {
-      float4 b = zin ? *reinterpret_cast<const float4*>(zin + i) : make_float4(mean, mean, mean, mean);
+      float4 b = make_float4(mean, mean, mean, mean);
+      if (zin) {
+        if (nt) { const nz_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nz_f32x4*>(zin + i)); b = make_float4(v[0], v[1], v[2], v[3]); }
+        else b = *reinterpret_cast<const float4*>(zin + i);
+      }
       b.x = fmaf(std, z[0], b.x); b.y = fmaf(std, z[1], b.y); b.z = fmaf(std, z[2], b.z); b.w = fmaf(std, z[3], b.w);
-      *reinterpret_cast<float4*>(out + i) = b;
+      if (nt) __builtin_nontemporal_store((nz_f32x4){b.x, b.y, b.z, b.w}, reinterpret_cast<nz_f32x4*>(out + i));
+      else *reinterpret_cast<float4*>(out + i) = b;
     } else {
       for (int k = 0; k < 4 && i + k < n; ++k) out[i + k] = fmaf(std, z[k], zin ? zin[i + k] : mean);
     }

@@ -1,3 +1,5 @@
-python -m pytest tests/test_gpu_ops.py tests/test_gpu_bench_size.py -x -q -m gpu 2>&1 | tail -3
-C="res0_25_16 dec0_67_4 enc0_64_4 enc0_8_13 enc0_4_8 out_25_1 res1_51_32 enc1_17_26 dec1_137_8 res2_105_64 enc3_71_106"
-for w in 0 1; do echo "== wide $w"; DPI_BW_WIDE=$w python tools/bench_conv.py --cases $C --which bwd_weight --reps 20 2>/dev/null | grep -v "^case"; done
+python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k q4 2>&1 | tail -2
+bash tools/profile_r03.sh r03nt stats 2>&1 | grep "total kernel\|conv_q4\|bn_bwd\|chain_\|noise" | cut -c1-130
+for i in 1 2; do python bench.py --steps 20 --no-cpu-baseline --no-other-modes --no-c3-extra 2>/dev/null | python -c "
+import json,sys
+r=json.loads(sys.stdin.read()); print(r['ms_per_step'])"; done
