@@ -1,5 +1,2 @@
-python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k q4 2>&1 | tail -2
-bash tools/profile_r03.sh r03nt stats 2>&1 | grep "total kernel\|conv_q4\|bn_bwd\|chain_\|noise" | cut -c1-130
-for i in 1 2; do python bench.py --steps 20 --no-cpu-baseline --no-other-modes --no-c3-extra 2>/dev/null | python -c "
-import json,sys
-r=json.loads(sys.stdin.read()); print(r['ms_per_step'])"; done
+python -m pytest tests/test_gpu_ops.py tests/test_gpu_bench_size.py -x -q -m gpu -k "conv" 2>&1 | tail -2
+python tools/bench_conv.py --cases sc0_67_25 sc0_64_25 res0_25_16_k1 sc1_137_51 --reps 20 2>/dev/null
