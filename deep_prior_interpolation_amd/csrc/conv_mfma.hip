@@ -109,14 +109,25 @@ __device__ __forceinline__ void stage_load(float (&sr)[4][G::E], const float* __
 template <class G>
 __device__ __forceinline__ void stage_store(float* lds, const float (&sr)[4][G::E], const float* __restrict__ chain, int Cin, int c0,
                                             const int (&goff)[G::E], const int (&loff)[G::E]) {
+  // ONE wave-uniform branch: without a chain (every backward-data launch, every layer that reads a materialised tensor) the staging is
+  // plain stores.  Written as a per-element `chain && in_volume ? T(x) : x`, hipcc evaluated T(x) for every element and selected
+  // (5 VALU instructions x 32 elements per tile that compete with the MFMAs of the other waves for the SIMD; round 3).
+  if (chain == nullptr) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < G::E; ++e)
+        if ((e + 1) * 256 <= G::TILE || loff[e] >= 0) lds[c * G::CS + loff[e]] = sr[c][e];   // only the last slot can be past the tile
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int ci = min(c0 + c, Cin - 1);
     const Chain t = load_chain(chain, ci);
 #pragma unroll
     for (int e = 0; e < G::E; ++e) {
-      const float v = (chain && goff[e] >= 0) ? apply_chain(t, sr[c][e]) : sr[c][e];
-      if ((e + 1) * 256 <= G::TILE || loff[e] >= 0) lds[c * G::CS + loff[e]] = v;   // only the last slot can be past the tile
+      const float v = goff[e] >= 0 ? apply_chain(t, sr[c][e]) : sr[c][e];
+      if ((e + 1) * 256 <= G::TILE || loff[e] >= 0) lds[c * G::CS + loff[e]] = v;
     }
   }
 }
