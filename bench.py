@@ -233,8 +233,8 @@ def run_c2(a, rank, world, device):
     mode = a.mode
     if mode == "auto":                      # big patches are GPU-bound either way; small ones are launch-bound without a graph
         mode = "eager" if V >= (1 << 20) else "graph"
-    overlap = mode == "eager" and V >= (1 << 20) and WGRAD_OVERLAP
-    ops.set_weight_grad_overlap(overlap)
+    overlap = V >= (1 << 20) and WGRAD_OVERLAP     # --mode graph on a big patch: the side stream is captured into the graph too
+    ops.set_weight_grad_overlap(overlap, in_graph=(mode == "graph" and overlap))
 
     def eager_step():
         T.optimizer.zero_grad()

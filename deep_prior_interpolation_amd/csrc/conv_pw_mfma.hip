@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void conv_pw_mfma_kernel(PwMArgs a) {
   const int n0 = blockIdx.y * 16 * MT;
   const bool vec = (a.V & 3) == 0;
   const int nchunk = (a.Cin + 3) >> 2;
-  __shared__ float wl[WLDS ? kPwLdsFloats : 1];
+  extern __shared__ float wl[];                        // WLDS: nchunk * MT * 64 floats (launch argument)
   if constexpr (WLDS) {
     for (int e = tid; e < nchunk * MT * 64; e += 256) {
       const int l = e & 63, m = (e >> 6) % MT, ch = (e >> 6) / MT;
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_weight_mfma_kernel(PwBwArgs a
 
   const size_t vbeg = (size_t)blockIdx.x * a.vox_per_chunk;
   const size_t vend = vbeg + a.vox_per_chunk < a.V ? vbeg + a.vox_per_chunk : a.V;
-  // A wave takes 64 voxels per round: lane (row lj, k = lk) owns voxels g0 + 16*lk + [0,16) -> four consecutive float4
-  // per operand row (64 B per lane, 256 B contiguous per channel), all requested before the first MFMA of the round.
+  // A wave takes 64 voxels per round: lane (row lj, k = lk) owns four float4 per operand row (256 B contiguous per channel
+  // and round), all requested before the first MFMA of the round.
   // Rows past Cout / Cin re-read the last real channel (their products land in rows that are never written).
   const float* __restrict__ dyr[MT];
   const float* __restrict__ xr[NT];
@@ -203,18 +203,22 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_weight_mfma_kernel(PwBwArgs a
   for (int n = 0; n < NT; ++n) xr[n] = a.x + (size_t)min(ci0 + n * 16 + lj, a.Cin - 1) * a.V;
   const int mt_valid = min(MT, (a.Cout - co0 + 15) / 16), nt_valid = min(NT, (a.Cin - ci0 + 15) / 16);
   for (size_t g0 = vbeg + (size_t)wid * 64; g0 < vend; g0 += 256) {
-    const size_t v0 = g0 + 16 * lk;
+    // element e = 4j + i of a lane is voxel g0 + 16j + 4lk + i: float4 j of the four lk lanes of a row is ONE 64-byte piece
+    // (16 rows x 1 line per load instruction; with voxel = 16lk + e the same instruction touched 4 pieces 64 B apart per row)
+    const size_t v0 = g0 + 4 * lk;
+    auto vox = [&](int e) { return v0 + 16 * (e >> 2) + (e & 3); };
+    const bool whole = vec && g0 + 63 < vend;
     float ga[MT][16], xb[NT][16];
     auto load16 = [&](const float* __restrict__ p, float (&o)[16]) {
-      if (vec && v0 + 15 < vend) {
+      if (whole) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float4 f = *reinterpret_cast<const float4*>(p + v0 + 4 * j);
+          const float4 f = *reinterpret_cast<const float4*>(p + v0 + 16 * j);
           o[4 * j] = f.x; o[4 * j + 1] = f.y; o[4 * j + 2] = f.z; o[4 * j + 3] = f.w;
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { const float v = p[v0 + e < vend ? v0 + e : vbeg]; o[e] = v0 + e < vend ? v : 0.f; }
+        for (int e = 0; e < 16; ++e) { const float v = p[vox(e) < vend ? vox(e) : vbeg]; o[e] = vox(e) < vend ? v : 0.f; }
       }
     };
     // 16-channel tiles that lie entirely past Cout / Cin (e.g. Cin = 67: the second 64-channel block holds 3 channels)
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_weight_mfma_kernel(PwBwArgs a
       for (int n = 0; n < NT; ++n)
         if (n < nt_valid) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e) xb[n][e] = (v0 + e < vend) ? apply_chain(ch[n], xb[n][e]) : 0.f;
+          for (int e = 0; e < 16; ++e) xb[n][e] = (vox(e) < vend) ? apply_chain(ch[n], xb[n][e]) : 0.f;
         }
     }
 #pragma unroll
@@ -320,9 +324,12 @@ int dpi_conv_pw_mfma_run(const dpi_conv_desc* d, const float* x, const float* ch
   const unsigned gx = (unsigned)cdivz(a.V, vpb);
   const bool wlds = (long)cdiv(cin, 4) * mt * 64 <= kPwLdsFloats;
   const dim3 grid(gx, cdiv(cout, 16 * mt));
-  if (mt == 1) { if (wlds) conv_pw_mfma_kernel<1, true><<<grid, 256, 0, st>>>(a); else conv_pw_mfma_kernel<1, false><<<grid, 256, 0, st>>>(a); }
-  else if (mt == 2) { if (wlds) conv_pw_mfma_kernel<2, true><<<grid, 256, 0, st>>>(a); else conv_pw_mfma_kernel<2, false><<<grid, 256, 0, st>>>(a); }
-  else { if (wlds) conv_pw_mfma_kernel<4, true><<<grid, 256, 0, st>>>(a); else conv_pw_mfma_kernel<4, false><<<grid, 256, 0, st>>>(a); }
+  // the weight tile is the kernel's only sizeable LDS: allocated to size (8-9 KB for the full-resolution layers), so that registers
+  // and not a fixed 48 KB bound the number of resident workgroups (= loads in flight per CU of an HBM-bound kernel)
+  const size_t wbytes = wlds ? (size_t)cdiv(cin, 4) * mt * 64 * sizeof(float) : 0;
+  if (mt == 1) { if (wlds) conv_pw_mfma_kernel<1, true><<<grid, 256, wbytes, st>>>(a); else conv_pw_mfma_kernel<1, false><<<grid, 256, 0, st>>>(a); }
+  else if (mt == 2) { if (wlds) conv_pw_mfma_kernel<2, true><<<grid, 256, wbytes, st>>>(a); else conv_pw_mfma_kernel<2, false><<<grid, 256, 0, st>>>(a); }
+  else { if (wlds) conv_pw_mfma_kernel<4, true><<<grid, 256, wbytes, st>>>(a); else conv_pw_mfma_kernel<4, false><<<grid, 256, 0, st>>>(a); }
   return dpi_check_launch("conv_pw_mfma");
 }
 

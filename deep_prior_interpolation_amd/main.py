@@ -221,7 +221,8 @@ class Interpolator:
             mode = "eager" if (net_inputs is not None or a.save_every is not None or a.epochs < 3 or self.has_regularizer()
                                or a.data_forgetting_factor != 0 or int(np.prod(self.img.shape[:-1])) >= (1 << 20)) else "graph"
         self.optimizer = FusedAdam(self.net.parameters(), lr=a.lr)
-        ops.set_weight_grad_overlap(mode == "eager" and int(np.prod(self.img.shape[:-1])) >= (1 << 20))
+        big = int(np.prod(self.img.shape[:-1])) >= (1 << 20)
+        ops.set_weight_grad_overlap(big, in_graph=(mode == "graph" and big))
         start = time()
         if mode == "graph":
             self._optimize_graph(verbose, check_every)

@@ -166,13 +166,18 @@ def raw_conv_bwd_data(d, dy, w, dx, accumulate=False):
 # 256x128x128) and costs host time when it is launch-bound (64^3 eager: 8.8 -> 11.3 ms).  Interpolator.optimize / bench.py
 # switch it on by patch size; DPI_OVERLAP_WGRAD=0/1 forces it.
 OVERLAP_WEIGHT_GRADS = os.environ.get("DPI_OVERLAP_WGRAD", "0") == "1"
+OVERLAP_IN_GRAPH = os.environ.get("DPI_OVERLAP_IN_GRAPH", "0") == "1"
 OVERLAP_MAX_VOXELS = int(os.environ.get("DPI_OVERLAP_MAX_VOXELS", str(1 << 40)))
 
 
-def set_weight_grad_overlap(on):
-    global OVERLAP_WEIGHT_GRADS
+def set_weight_grad_overlap(on, in_graph=None):
+    """in_graph: keep the side stream inside a hipGraph capture too (fork / join edges in the graph).  Pays on GPU-bound patches
+    (256x128x128: 34.2 ms eager with overlap, 34.2 ms graph without, 33.8 ms graph with), costs on small ones (64^3: 7.6 vs 7.9 ms)."""
+    global OVERLAP_WEIGHT_GRADS, OVERLAP_IN_GRAPH
     if "DPI_OVERLAP_WGRAD" not in os.environ:
         OVERLAP_WEIGHT_GRADS = bool(on)
+    if in_graph is not None and "DPI_OVERLAP_IN_GRAPH" not in os.environ:
+        OVERLAP_IN_GRAPH = bool(in_graph)
 _side_streams = {}
 
 
@@ -190,7 +195,7 @@ def conv_bwd_weight_async(d, x, chain, dy, dw):
     Callers must `join_weight_grads()` before returning to autograd."""
     # (DPI_OVERLAP_MAX_VOXELS: A/B knob — restricting the side stream to the coarse levels, whose kernels leave CUs idle, measured
     #  35.76 ms per iteration against 35.10 with every layer on it, round 3)
-    if not OVERLAP_WEIGHT_GRADS or d.D * d.H * d.W >= OVERLAP_MAX_VOXELS or torch.cuda.is_current_stream_capturing():
+    if not OVERLAP_WEIGHT_GRADS or d.D * d.H * d.W >= OVERLAP_MAX_VOXELS or (torch.cuda.is_current_stream_capturing() and not OVERLAP_IN_GRAPH):
         # (inside a hipGraph capture the fork / join edges cost more than the overlap wins on the small patches that are
         #  run as graphs: measured 7.6 vs 7.9 ms per iteration at 64^3)
         return raw_conv_bwd_weight(d, x, chain, dy, dw)
@@ -201,7 +206,7 @@ def conv_bwd_weight_async(d, x, chain, dy, dw):
 
 
 def join_weight_grads():
-    if OVERLAP_WEIGHT_GRADS and not torch.cuda.is_current_stream_capturing():
+    if OVERLAP_WEIGHT_GRADS and (OVERLAP_IN_GRAPH or not torch.cuda.is_current_stream_capturing()):
         torch.cuda.current_stream().wait_stream(_side_stream())
 
 

@@ -26,9 +26,11 @@ def short(name):
 
 
 grids = {}
+durs = {}
 if a.by_grid:                                                          # pmc_events carries no launch geometry: join on dispatch_id
-    for disp, gx, wx in cur.execute("select dispatch_id, grid_x, workgroup_x from kernels"):
+    for disp, gx, wx, dur in cur.execute("select dispatch_id, grid_x, workgroup_x, duration from kernels"):
         grids[disp] = gx // max(wx, 1)
+        durs[disp] = dur
 agg = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))      # key -> counter -> dispatch -> value
 for name, disp, cname, val in cur.execute("select name, dispatch_id, counter_name, counter_value from pmc_events"):
     if a.match in name:
@@ -51,6 +53,10 @@ if a.totals:
 else:
     for k, cs in agg.items():
         print(k)
+        if durs:                                                        # duration of the SAME (counter-collecting) dispatches, ns
+            dd = [durs[x] for x in next(iter(cs.values())) if x in durs]
+            if dd:
+                print("   %-28s n=%d avg=%.6g" % ("duration_ns", len(dd), sum(dd) / len(dd)))
         for cname, d in sorted(cs.items()):
             v = list(d.values())
             print("   %-28s n=%d avg=%.6g" % (cname, len(v), sum(v) / len(v)))
