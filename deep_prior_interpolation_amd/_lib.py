@@ -15,7 +15,7 @@ class DpiError(RuntimeError):
     pass
 
 
-ABI_VERSION = 300      # include/dpi_hip.h as of round 3: dpi_conv_desc starts with its own size
+ABI_VERSION = 301      # include/dpi_hip.h: dpi_conv_desc starts with its own size (300); dpi_conv_fwd_ws / dpi_conv_bwd_data_ws (301)
 
 
 class ConvDesc(C.Structure):
@@ -50,6 +50,11 @@ SIGNATURES = {
     "dpi_conv_fwd_stat_blocks": (_I, [_DESC]),
     "dpi_conv_fwd": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P]),
     "dpi_conv_bwd_data": (_I, [_DESC, _P, _P, _P, _I, _P]),
+    "dpi_conv_fwd_ws_floats": (_Z, [_DESC]),
+    "dpi_conv_bwd_data_ws_floats": (_Z, [_DESC]),
+    "dpi_conv_fwd_ws": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "dpi_conv_bwd_data_ws": (_I, [_DESC, _P, _P, _P, _I, _P, _Z, _P]),
+    "dpi_set_splitk": (None, [_I]),
     "dpi_conv_bwd_weight_ws_floats": (_Z, [_DESC]),
     "dpi_conv_bwd_weight": (_I, [_DESC, _P, _P, _P, _P, _P, _Z, _P]),
     "dpi_set_mfma_min_cout": (None, [_I]),

@@ -442,7 +442,8 @@ int dpi_check_conv_desc(const dpi_conv_desc* d) {
 
 // MFMA stencil path (conv_mfma.hip): k = 3, stride 1, enough output channels to fill a 16-row MFMA tile
 int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
-                      double* partials, bool flip, int accumulate, hipStream_t st);
+                      double* partials, bool flip, int accumulate, float* ws, size_t ws_floats, hipStream_t st);
+size_t dpi_conv_mfma_ws_floats(const dpi_conv_desc* d, bool flip);
 void dpi_conv_pw_mfma_plan(size_t V, int cout, int* vox_per_block, int* mt);
 bool dpi_conv_fewco_usable(const dpi_conv_desc* d);
 bool dpi_conv_q4_usable(const dpi_conv_desc* d, bool flip);
@@ -497,8 +498,15 @@ extern "C" int dpi_conv_fwd_stat_blocks(const dpi_conv_desc* d) {
   return cdiv(Do, g.tz) * cdiv(Ho, g.ty) * cdiv(Wo, g.txow);
 }
 
+// which launches take the fp32-MFMA stencil path of conv_mfma.hip (the order of the tests in conv_run)
+static bool takes_mfma_path(const dpi_conv_desc* d, bool flip) {
+  const int cout = flip ? d->Cin : d->Cout;
+  if (dpi_conv_bf16_usable(d, flip) || dpi_conv_q4_usable(d, flip)) return false;
+  return d->k == 3 && cout >= g_mfma_min_cout && (d->stride == 1 || !flip);
+}
+
 static int conv_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias,
-                    float* y, double* partials, bool flip, int accumulate, hipStream_t st) {
+                    float* y, double* partials, bool flip, int accumulate, float* ws, size_t ws_floats, hipStream_t st) {
   // For flip (backward-data of a stride-1 conv) the caller passes dy as x and swaps channel roles:
   // "Cin" of this launch = d->Cout, "Cout" = d->Cin, spatial dims unchanged.
   int Do, Ho, Wo;
@@ -509,7 +517,7 @@ static int conv_run(const dpi_conv_desc* d, const float* x, const float* chain, 
   if (dpi_conv_bf16_usable(d, flip)) return dpi_conv_bf16_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
   if (dpi_conv_q4_usable(d, flip)) return dpi_conv_q4_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
   if (d->k == 3 && cout >= g_mfma_min_cout && (d->stride == 1 || !flip))
-    return dpi_conv_mfma_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
+    return dpi_conv_mfma_run(d, x, chain, w, bias, y, partials, flip, accumulate, ws, ws_floats, st);
   if (d->k == 1 && cout >= g_mfma_min_cout) return dpi_conv_pw_mfma_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
   if (!flip && !accumulate && g_fewco_mfma && dpi_conv_fewco_usable(d)) return dpi_conv_fewco_mfma_run(d, x, chain, w, bias, y, partials, st);
   const int co_b = pick_co_b(cout);
@@ -533,19 +541,41 @@ static int conv_run(const dpi_conv_desc* d, const float* x, const float* chain, 
   return dpi_check_launch("conv_direct");
 }
 
-extern "C" int dpi_conv_fwd(const dpi_conv_desc* d, const float* x, const float* x_chain, const float* w,
-                            const float* bias, float* y, double* stat_partials, void* stream) {
+extern "C" size_t dpi_conv_fwd_ws_floats(const dpi_conv_desc* d) {
+  if (check_desc(d) != DPI_OK) return 0;
+  return takes_mfma_path(d, false) ? dpi_conv_mfma_ws_floats(d, false) : 0;
+}
+
+extern "C" size_t dpi_conv_bwd_data_ws_floats(const dpi_conv_desc* d) {
+  if (check_desc(d) != DPI_OK || d->stride != 1) return 0;
+  return takes_mfma_path(d, true) ? dpi_conv_mfma_ws_floats(d, true) : 0;
+}
+
+extern "C" int dpi_conv_fwd_ws(const dpi_conv_desc* d, const float* x, const float* x_chain, const float* w, const float* bias, float* y,
+                               double* stat_partials, float* ws, size_t ws_floats, void* stream) {
   if (int e = check_desc(d)) return e;
   DPI_REQUIRE(x && w && y, "conv_fwd: null tensor");
-  return conv_run(d, x, x_chain, w, bias, y, stat_partials, false, 0, (hipStream_t)stream);
+  DPI_REQUIRE(ws || ws_floats == 0, "conv_fwd: workspace size without a workspace");
+  return conv_run(d, x, x_chain, w, bias, y, stat_partials, false, 0, ws, ws_floats, (hipStream_t)stream);
+}
+
+extern "C" int dpi_conv_fwd(const dpi_conv_desc* d, const float* x, const float* x_chain, const float* w,
+                            const float* bias, float* y, double* stat_partials, void* stream) {
+  return dpi_conv_fwd_ws(d, x, x_chain, w, bias, y, stat_partials, nullptr, 0, stream);
 }
 
 extern "C" int dpi_conv_bwd_data(const dpi_conv_desc* d, const float* dy, const float* w, float* dx,
                                  int accumulate, void* stream) {
+  return dpi_conv_bwd_data_ws(d, dy, w, dx, accumulate, nullptr, 0, stream);
+}
+
+extern "C" int dpi_conv_bwd_data_ws(const dpi_conv_desc* d, const float* dy, const float* w, float* dx,
+                                    int accumulate, float* ws, size_t ws_floats, void* stream) {
   if (int e = check_desc(d)) return e;
   DPI_REQUIRE(dy && w && dx, "conv_bwd_data: null tensor");
+  DPI_REQUIRE(ws || ws_floats == 0, "conv_bwd_data: workspace size without a workspace");
   hipStream_t st = (hipStream_t)stream;
-  if (d->stride == 1) return conv_run(d, dy, nullptr, w, nullptr, dx, nullptr, true, accumulate, st);
+  if (d->stride == 1) return conv_run(d, dy, nullptr, w, nullptr, dx, nullptr, true, accumulate, ws, ws_floats, st);
   if (d->Cin >= g_mfma_min_cout) return dpi_conv_bwd_data_s2_mfma_run(d, dy, w, dx, accumulate, st);
   int Do, Ho, Wo;
   dpi_conv_out_dims(d, &Do, &Ho, &Wo);

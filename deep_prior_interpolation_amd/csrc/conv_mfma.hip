@@ -35,6 +35,10 @@ struct MArgs {
   int ntd, nth, ntw;
   long w_out_stride, w_in_stride;
   int accumulate;
+  // input-channel split ("split-K", coarse levels): split_cps > 0 -> workgroup column blockIdx.z sums input channels
+  // [z * split_cps, (z + 1) * split_cps) only and writes its partial result to y + z * Cout * Vo (y = the workspace; no bias,
+  // no statistics, no fan-in: splitk_reduce_kernel adds those).  0: blockIdx.z = 0 covers every channel.
+  int split_cps;
 };
 
 // Tile geometry.  A wave owns NR output rows x NH 16-voxel column blocks; the 4 waves of a workgroup own
@@ -143,8 +147,10 @@ __device__ __forceinline__ void stage_store(float* lds, const float (&sr)[4][G::
 __device__ long long g_blk[8192][4];
 __device__ long long g_trace[4][64];
 #define TR(i) do { if (trc >= 0 && tid == 0) g_trace[trc][i] = clock64(); } while (0)
+#define TRC(i) do { if (trc >= 0 && tid == 0 && (i) < 38) g_trace[trc][i] = clock64(); } while (0)   // per-chunk slots: first 9 chunks
 #else
 #define TR(i)
+#define TRC(i)
 #endif
 // TAILPACK: a channel count of 4m + 1 (25, 13, 17, 105: the MultiRes widths) leaves ONE channel for the last K = 4 group.
 // Instead of 27 MFMAs per output tile with three zero K-slices, that channel's taps are packed four to an MFMA
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
   const int Do = (a.D + 2 * PD - KD) / G::SD + 1, Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
   const size_t Vo = (size_t)Do * Ho * Wo;
 #ifdef DPI_TRACE
-  const int trc = blockIdx.y != 0 ? -1 : blockIdx.x == 0 ? 0 : blockIdx.x == 1 ? 1 : blockIdx.x == 300 ? 2 : blockIdx.x == 500 ? 3 : -1;
+  const int trc = blockIdx.y != 0 ? -1 : blockIdx.x == 0 ? 0 : blockIdx.x == 1 ? 1 : blockIdx.x == 30 ? 2 : blockIdx.x == 50 ? 3 : -1;
   TR(0);
   if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 8192) {
     g_blk[blockIdx.x][0] = wall_clock64();
@@ -208,15 +214,17 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
     for (int t = 0; t < 9; ++t) wr[kd * 9 + t] = ok ? wn[t] : 0.f;
   };
 
+  const int c_lo = a.split_cps ? (int)blockIdx.z * a.split_cps : 0;
+  float* __restrict__ const ybase = a.y + (size_t)blockIdx.z * a.Cout * Vo;
   int goff[G::E], loff[G::E];
   float wr[TAPS], wn[9], sr[4][G::E];
   int vt = blockIdx.x, tile_id, od0, oh0, ow0;
   tile_origin(vt, tile_id, od0, oh0, ow0);
   tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
-  stage_load<G>(sr, a.x, a.Cin, V, 0, goff);
+  stage_load<G>(sr, a.x, a.Cin, V, c_lo, goff);
   {
     bool ok;
-    const float* __restrict__ wp = w_ptr(0, ok);
+    const float* __restrict__ wp = w_ptr(c_lo, ok);
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) wr[t] = wp[FLIP ? (TAPS - 1 - t) : t];     // all in flight together
 #pragma unroll
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
 
   constexpr int NTG = (TAPS + 3) / 4;                // tap groups of the packed tail
   const bool tail = TAILPACK && S == 1 && (a.Cin & 3) == 1 && a.Cin > 4;
-  const int cin_main = tail ? a.Cin - 1 : a.Cin;
+  const int cin_main = a.split_cps ? min(c_lo + a.split_cps, a.Cin) : (tail ? a.Cin - 1 : a.Cin);   // (the split never runs the tap-packed variants)
   int ttoff[TAILPACK ? NTG : 1];
   float wt[TAILPACK ? NTG : 1];
   if constexpr (TAILPACK) {
@@ -272,25 +280,25 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
-          if (co < a.Cout && od < Do && oh < Ho && ow < Wo) acc[t][r] = a.y[(size_t)co * Vo + ((size_t)od * Ho + oh) * Wo + ow];
+          if (co < a.Cout && od < Do && oh < Ho && ow < Wo) acc[t][r] = ybase[(size_t)co * Vo + ((size_t)od * Ho + oh) * Wo + ow];
         }
       }
     }
 
     TR(1);
-    for (int c0 = 0; c0 < cin_main; c0 += 4) {
+    for (int c0 = c_lo; c0 < cin_main; c0 += 4) {
       __syncthreads();                                   // everyone is done reading the previous chunk
-      TR(2 + (c0 / 4) * 4);
+      TRC(2 + (c0 / 4) * 4);
       stage_store<G>(lds, sr, a.chain, a.Cin, c0, goff, loff);
-      TR(3 + (c0 / 4) * 4);
+      TRC(3 + (c0 / 4) * 4);
       __syncthreads();
-      TR(4 + (c0 / 4) * 4);
+      TRC(4 + (c0 / 4) * 4);
       const bool more = c0 + 4 < cin_main;
       const bool tail_next = tail && !more;
       if (more || tail_next) stage_load<G>(sr, a.x, a.Cin, V, c0 + 4, goff);   // prefetch the next group behind this one's MFMAs
       else if (has_next) {                                        // ... or the first chunk of the next tile
         tile_slots<G>(tid, od_n * G::SD - PD, oh_n * S - 1, ow_n * S - 1, a.D, a.H, a.W, goff, loff);
-        stage_load<G>(sr, a.x, a.Cin, V, 0, goff);
+        stage_load<G>(sr, a.x, a.Cin, V, c_lo, goff);
       }
       // software-pipelined walk over (kd, input row): LDS values of step s+1 are requested before the MFMAs of step s
       float bc[G::NB], bn[G::NB];
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
           for (int kw = 0; kw < 3; ++kw) b[h * 3 + kw] = lds[lbase + kd * G::DS + ir * G::RS + h * 16 * S + kw];
       };
       load_b(bc, 0);
-      const int cn = more ? c0 + 4 : 0;                  // chunk whose weights are fetched next (chunk 0: next tile / harmless)
+      const int cn = more ? c0 + 4 : c_lo;                  // chunk whose weights are fetched next (chunk 0: next tile / harmless)
       if (tail_next) load_tail_w();
 #pragma unroll
       for (int step = 0; step < G::NSTEP; ++step) {
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
         if (ir == G::NROW - 1) commit_w(wr, wn, cn, kd);
       }
       if (tail_next) commit_tail_w();
-      TR(5 + (c0 / 4) * 4);
+      TRC(5 + (c0 / 4) * 4);
     }
     if constexpr (TAILPACK) {
       if (tail) {
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
       const int co = n0 + 4 * lk + r;
       const bool cok = co < a.Cout;
       const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
-      float* __restrict__ yc = a.y + (size_t)(cok ? co : 0) * Vo + vbase;
+      float* __restrict__ yc = ybase + (size_t)(cok ? co : 0) * Vo + vbase;
       double s = 0.0, q = 0.0;
       if (interior) {
 #pragma unroll
@@ -900,6 +908,32 @@ __global__ __launch_bounds__(256) void conv_bwd_data_s2_mfma_kernel(BdS2Args a) 
   }
 }
 
+// ---- split-K reduction: y[co][v] = (y[co][v] +) bias[co] + sum_s ws[s][co][v], fixed order; BatchNorm statistics of y ------------
+// grid (nblk, ceil(Cout / 4)), one wave per channel; block b owns voxels [b * per, (b + 1) * per) and writes the stat partial
+// (b, co) — any partition into nblk blocks serves dpi_bn_finalize, which only sums over blocks.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int accumulate, double* __restrict__ partials,
+                                                            int Cout, size_t Vo, size_t per) {
+  const int lane = threadIdx.x & 63, co = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (co >= Cout) return;
+  const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < Vo ? lo + per : Vo;
+  const float bv = bias ? bias[co] : 0.f;
+  double sum = 0.0, sq = 0.0;
+  for (size_t v = lo + lane; v < hi; v += 64) {
+    float t = ws[(size_t)co * Vo + v];
+    for (int sp = 1; sp < nsplit; ++sp) t += ws[((size_t)sp * Cout + co) * Vo + v];
+    t += bv;
+    if (accumulate) t += y[(size_t)co * Vo + v];
+    y[(size_t)co * Vo + v] = t;
+    sum += t; sq += (double)t * t;
+  }
+  if (partials) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); sq += __shfl_xor(sq, o, 64); }
+    if (lane == 0) { partials[((size_t)blockIdx.x * Cout + co) * 2] = sum; partials[((size_t)blockIdx.x * Cout + co) * 2 + 1] = sq; }
+  }
+}
+
 }  // namespace
 
 // ---- host-side entry points used by the dispatchers in conv_direct.hip / conv_bwd_weight.hip ---------------------------
@@ -971,17 +1005,64 @@ static void launch_variant(const MArgs& a, int nr, int nh, int stride, dim3 grid
 extern "C" int dpi_debug_read_blocks(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk), sizeof(long long) * 8192 * 4); }
 extern "C" int dpi_debug_read_trace(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(long long) * 4 * 64); }
 #endif
+// Input-channel split of the small-tile variants (the coarse levels of the U-Net): a launch of 64 tiles x 3 channel tiles whose
+// workgroups each walk 139 four-channel chunks (554 -> 35 at 32x16x16) leaves a quarter of the CUs idle for 290 us.  Split the
+// channel loop over blockIdx.z into partial outputs (workspace) and sum them in fixed order: nsplit x as many workgroups, each
+// with 1 / nsplit of the serial chain.  Returns the number of splits (1: none).
+static int g_splitk = getenv("DPI_SPLITK") ? atoi(getenv("DPI_SPLITK")) : 1;
+extern "C" void dpi_set_splitk(int on) { g_splitk = on; }
+int dpi_mfma_splitk(const dpi_conv_desc* d, bool flip) {
+  if (!g_splitk || d->k != 3) return 1;
+  const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
+  int nr, nh, a, b, c;
+  dpi_mfma_variant(d, cout, &nr, &nh);
+  if (nr != 2 || dpi_mfma_half_tile(d, flip)) return 1;           // the persistent / tap-packed big-tile variants fill the chip
+  const long wgs = (long)dpi_mfma_tiles(d, nr, nh, &a, &b, &c) * cdiv(cout, 16);
+  const int chunks = cdiv(cin, 4);
+  // measured on the coarse-level shapes of the default net (tools/bench_conv.py, DPI_SPLITK=0 / 1): the split pays when the launch
+  // is about one workgroup per CU or less and every split keeps >= 8 chunks; 2-3 splits of a 13-18 chunk loop lose 5-15 % to the
+  // extra reduction launch
+  if (wgs > 512 || (wgs > 256 && chunks < 24)) return 1;
+  long ns = 1536 / wgs;
+  if (ns > chunks / 8) ns = chunks / 8;
+  if (ns > 8) ns = 8;
+  return ns < 2 ? 1 : (int)ns;
+}
+size_t dpi_conv_mfma_ws_floats(const dpi_conv_desc* d, bool flip) {
+  const int ns = dpi_mfma_splitk(d, flip);
+  if (ns < 2) return 0;
+  int Do, Ho, Wo;
+  dpi_conv_out_dims(d, &Do, &Ho, &Wo);
+  return (size_t)ns * (flip ? d->Cin : d->Cout) * Do * Ho * Wo;
+}
+
 int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
-                      double* partials, bool flip, int accumulate, hipStream_t st) {
+                      double* partials, bool flip, int accumulate, float* ws, size_t ws_floats, hipStream_t st) {
   const int taps = d->kd * 9;
   const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
   const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
-  MArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, accumulate};
+  MArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, accumulate, 0};
   int nr, nh;
   dpi_mfma_variant(d, cout, &nr, &nh);
   if (dpi_mfma_half_tile(d, flip)) nr = 4;
   const int ntiles = dpi_mfma_tiles(d, nr, nh, &a.ntd, &a.nth, &a.ntw);
   dim3 grid(ntiles, cdiv(cout, 16));
+  const int nsplit = ws ? dpi_mfma_splitk(d, flip) : 1;
+  if (nsplit > 1) {
+    int Do, Ho, Wo;
+    dpi_conv_out_dims(d, &Do, &Ho, &Wo);
+    const size_t Vo = (size_t)Do * Ho * Wo;
+    DPI_REQUIRE(ws_floats >= (size_t)nsplit * cout * Vo, "conv (split): workspace of %zu floats, need %zu", ws_floats, (size_t)nsplit * cout * Vo);
+    a.split_cps = 4 * cdiv(cdiv(cin, 4), nsplit);
+    a.y = ws; a.bias = nullptr; a.partials = nullptr; a.accumulate = 0;
+    grid.z = cdiv(cin, a.split_cps);                                // <= nsplit; every column owns at least one chunk
+    const int nz = (int)grid.z;
+    if (d->kd == 3) { if (flip) launch_variant<3, true>(a, nr, nh, d->stride, grid, st); else launch_variant<3, false>(a, nr, nh, d->stride, grid, st); }
+    else { if (flip) launch_variant<1, true>(a, nr, nh, d->stride, grid, st); else launch_variant<1, false>(a, nr, nh, d->stride, grid, st); }
+    if (int e = dpi_check_launch("conv_mfma (split)")) return e;
+    splitk_reduce_kernel<<<dim3(ntiles, cdiv(cout, 4)), 256, 0, st>>>(ws, nz, bias, y, accumulate, partials, cout, Vo, cdivz(Vo, (size_t)ntiles));
+    return dpi_check_launch("splitk_reduce");
+  }
   if (d->kd == 3) { if (flip) launch_variant<3, true>(a, nr, nh, d->stride, grid, st); else launch_variant<3, false>(a, nr, nh, d->stride, grid, st); }
   else { if (flip) launch_variant<1, true>(a, nr, nh, d->stride, grid, st); else launch_variant<1, false>(a, nr, nh, d->stride, grid, st); }
   return dpi_check_launch("conv_mfma");

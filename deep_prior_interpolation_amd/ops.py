@@ -145,16 +145,25 @@ def _timed(kind, d, launch):
         launch()
 
 
+def _conv_ws(n, like):
+    """Workspace of the input-channel split (coarse levels; dpi_conv_*_ws_floats is 0 for every other launch)."""
+    return torch.empty(n, dtype=torch.float32, device=like.device) if n else None
+
+
 def raw_conv_fwd(d, x, chain, w, bias, y, partials=None):
     L = _lib.load()
-    _timed("conv_fwd", d, lambda: check(L.dpi_conv_fwd(C.byref(d), ptr(x), ptr(chain), ptr(w), ptr(bias), ptr(y),
-                                                       ptr(partials), stream()), "dpi_conv_fwd"))
+    n = L.dpi_conv_fwd_ws_floats(C.byref(d))
+    ws = _conv_ws(n, x)
+    _timed("conv_fwd", d, lambda: check(L.dpi_conv_fwd_ws(C.byref(d), ptr(x), ptr(chain), ptr(w), ptr(bias), ptr(y),
+                                                          ptr(partials), ptr(ws), n, stream()), "dpi_conv_fwd"))
 
 
 def raw_conv_bwd_data(d, dy, w, dx, accumulate=False):
     L = _lib.load()
-    _timed("conv_bwd_data", d, lambda: check(L.dpi_conv_bwd_data(C.byref(d), ptr(dy), ptr(w), ptr(dx), int(accumulate),
-                                                                 stream()), "dpi_conv_bwd_data"))
+    n = L.dpi_conv_bwd_data_ws_floats(C.byref(d))
+    ws = _conv_ws(n, dy)
+    _timed("conv_bwd_data", d, lambda: check(L.dpi_conv_bwd_data_ws(C.byref(d), ptr(dy), ptr(w), ptr(dx), int(accumulate),
+                                                                    ptr(ws), n, stream()), "dpi_conv_bwd_data"))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -43,7 +43,7 @@ extern "C" {
 #define DPI_CHAIN_STRIDE 5
 
 const char* dpi_last_error(void);
-/* ABI version: 300 = round 3 (dpi_conv_desc carries its own size as first field).  A binding checks `>=` the version it was
+/* ABI version: 300 = round 3 (dpi_conv_desc carries its own size as first field), 301 adds dpi_conv_fwd_ws / dpi_conv_bwd_data_ws.  A binding checks `>=` the version it was
  * written against and dpi_conv_desc_size() == its own struct size. */
 int dpi_version(void);
 /* Number of devices / properties as HIP sees them (no torch involved). */
@@ -92,6 +92,19 @@ int dpi_conv_fwd(const dpi_conv_desc* d, const float* x, const float* x_chain, c
 /* dx (+)= conv_transpose(dy, w):  dx [Cin][D][H][W], dy [Cout][Do][Ho][Wo].  accumulate != 0 adds. */
 int dpi_conv_bwd_data(const dpi_conv_desc* d, const float* dy, const float* w, float* dx,
                       int accumulate, void* stream);
+/* The same two operations with a caller-owned workspace (ABI 301).  At the coarse levels of the U-Net a convolution is a few
+ * dozen output tiles with hundreds of input channels: the library then splits the input-channel loop over more workgroups, writes
+ * partial outputs into `ws` and sums them in a fixed order (deterministic).  dpi_conv_*_ws_floats(d) = floats wanted (0: the
+ * problem is not split and ws may be NULL); with ws == NULL these are exactly dpi_conv_fwd / dpi_conv_bwd_data.  Results of the
+ * split and the unsplit launch differ by fp32 rounding of the partial sums only. */
+size_t dpi_conv_fwd_ws_floats(const dpi_conv_desc* d);
+size_t dpi_conv_bwd_data_ws_floats(const dpi_conv_desc* d);
+int dpi_conv_fwd_ws(const dpi_conv_desc* d, const float* x, const float* x_chain, const float* w,
+                    const float* bias, float* y, double* stat_partials, float* ws, size_t ws_floats, void* stream);
+int dpi_conv_bwd_data_ws(const dpi_conv_desc* d, const float* dy, const float* w, float* dx,
+                         int accumulate, float* ws, size_t ws_floats, void* stream);
+/* 0 switches the input-channel split off (A/B testing; default on, DPI_SPLITK=0 in the environment does the same) */
+void dpi_set_splitk(int on);
 /* dw[Cout][Cin][kd][k][k] = sum_p dy[co][p] * T(x)[ci][p*stride + tap - pad].
  * workspace: float[dpi_conv_bwd_weight_ws_floats(d)].  */
 size_t dpi_conv_bwd_weight_ws_floats(const dpi_conv_desc* d);

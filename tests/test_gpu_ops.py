@@ -150,6 +150,81 @@ def test_conv_fused_chain_and_stats(ops, cin, cout, shape):
     assert rel(dw, wr.grad) < 5e-6
 
 
+SPLIT_CASES = [(140, 35, (8, 16, 16), 1), (554, 35, (4, 8, 16), 1), (71, 20, (5, 7, 9), 1), (212, 71, (4, 4, 8), 1),
+               (100, 24, (8, 8, 16), 2), (133, 17, (3, 9, 11), 2), (77, 9, (1, 8, 16), 1)]
+
+
+@pytest.mark.parametrize("cin,cout,shape,stride", SPLIT_CASES)
+def test_conv_input_channel_split_vs_oracle(ops, cin, cout, shape, stride):
+    """Coarse-level launches (few output tiles, many input channels) split the input-channel loop over blockIdx.z into a workspace
+    and sum the partial outputs in a fixed order (dpi_conv_fwd_ws / dpi_conv_bwd_data_ws): forward with chain, bias and the
+    statistics epilogue, backward-data with fan-in, against the fp64 oracle; the unsplit launch of the same problem
+    (dpi_set_splitk(0), and the entry points without a workspace) agrees to rounding; two runs are bit-identical."""
+    import ctypes as C
+    from deep_prior_interpolation_amd import _lib
+    L = _lib.load()
+    gen = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn((1, cin) + shape, generator=gen)
+    chain = torch.stack([torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen), torch.full((cin,), 0.2),
+                         torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen)], dim=1).contiguous()
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen) * (1.0 / np.sqrt(cin * 27))
+    b = torch.randn(cout, generator=gen)
+    bc = lambda v: v.reshape(1, -1, 1, 1, 1)
+    tx = bc(chain[:, 3]) * O.activation("LeakyReLU", bc(chain[:, 0]) * x + bc(chain[:, 1])) + bc(chain[:, 4])
+    txr = tx.double().requires_grad_(True)
+    yr = O.conv_nd(txr, w.double(), b.double(), stride)
+    dy = torch.randn(yr.shape, generator=gen)
+    yr.backward(dy.double())
+    xg, wg, bg, cg, dyg = x.to(DEV), w.to(DEV), b.to(DEV), chain.to(DEV), dy.to(DEV)
+    d = ops.make_desc(xg, wg, stride)
+    assert L.dpi_conv_fwd_ws_floats(C.byref(d)) > 0, "case does not exercise the split"
+    nblk = L.dpi_conv_fwd_stat_blocks(C.byref(d))
+
+    def fwd():
+        part = torch.zeros(nblk * cout * 2, dtype=torch.float64, device=DEV)
+        y = torch.full(yr.shape, float("nan"), device=DEV)
+        ops.raw_conv_fwd(d, xg, cg, wg, bg, y, part)
+        return y, part
+    y, part = fwd()
+    assert rel(y, yr) < 2e-6
+    p = part.view(nblk, cout, 2).sum(0).cpu()
+    y64 = yr.detach()
+    np.testing.assert_allclose(p[:, 0].numpy(), y64.sum((0, 2, 3, 4)).numpy(), rtol=1e-5, atol=2e-2)
+    np.testing.assert_allclose(p[:, 1].numpy(), (y64 ** 2).sum((0, 2, 3, 4)).numpy(), rtol=1e-5)
+    y2, part2 = fwd()
+    assert torch.equal(y, y2) and torch.equal(part, part2)
+    # backward-data (stride 1: the flipped launch splits over the OUTPUT channels of the layer), plain and with fan-in
+    dxr = None
+    if stride == 1:
+        xr2 = x.double().requires_grad_(True)
+        O.conv_nd(xr2, w.double(), None, 1).backward(dy.double())
+        dxr = xr2.grad
+        dx = torch.full(x.shape, float("nan"), device=DEV)
+        ops.raw_conv_bwd_data(d, dyg, wg, dx)
+        assert rel(dx, dxr) < 2e-6
+        base = torch.randn(x.shape, generator=gen)
+        dx2 = base.to(DEV).clone()
+        ops.raw_conv_bwd_data(d, dyg, wg, dx2, accumulate=True)
+        assert rel(dx2, dxr + base.double()) < 2e-6
+    # the same launches without the split
+    L.dpi_set_splitk(0)
+    try:
+        assert L.dpi_conv_fwd_ws_floats(C.byref(d)) == 0
+        y0, part0 = fwd()
+        if dxr is not None:
+            dx0 = torch.empty(x.shape, device=DEV)
+            ops.raw_conv_bwd_data(d, dyg, wg, dx0)
+            assert rel(dx0, dxr) < 2e-6
+    finally:
+        L.dpi_set_splitk(1)
+    assert rel(y0, yr) < 2e-6 and rel(y, y0) < 2e-6
+    np.testing.assert_allclose(part0.view(nblk, cout, 2).sum(0).cpu().numpy(), p.numpy(), rtol=1e-6, atol=1e-3)
+    # an ABI-300 caller (no workspace) gets the unsplit launch
+    y3 = torch.empty(yr.shape, device=DEV)
+    _lib.check(L.dpi_conv_fwd(C.byref(d), _lib.ptr(xg), _lib.ptr(cg), _lib.ptr(wg), _lib.ptr(bg), _lib.ptr(y3), None, _lib.stream()), "dpi_conv_fwd")
+    assert torch.equal(y3, y0)
+
+
 @pytest.mark.parametrize("name", ["bn3d", "bn2d"])
 def test_bn_golden(golden, ops, name):
     g = golden("ops")[name]

@@ -20,6 +20,9 @@ CASES = {  # name: (Cin, Cout, k, stride, level)  level = spatial down-sampling 
     "dec1_137_8": (137, 8, 3, 1, 1), "down1_51_51": (51, 51, 3, 2, 1),
     "enc2_51_17": (51, 17, 3, 1, 2), "enc2_35_53": (35, 53, 3, 1, 2), "res2_105_64": (105, 64, 3, 1, 2), "dec2_276_17": (276, 17, 3, 1, 2),
     "enc3_71_106": (71, 106, 3, 1, 3), "res3_212_128": (212, 128, 3, 1, 3), "enc4_142_213": (142, 213, 3, 1, 4),
+    "dec3_554_35": (554, 35, 3, 1, 3), "dec4_212_71": (212, 71, 3, 1, 4), "enc4_71_142": (71, 142, 3, 1, 4), "enc3_35_71": (35, 71, 3, 1, 3),
+    "dec3_105_35": (105, 35, 3, 1, 3), "enc2_17_35": (17, 35, 3, 1, 2), "dec2_51_17": (51, 17, 3, 1, 2),
+    "down2_105_105": (105, 105, 3, 2, 2), "down3_212_212": (212, 212, 3, 2, 3),
     "sc0_64_25": (64, 25, 1, 1, 0), "sc0_67_25": (67, 25, 1, 1, 0), "res0_25_16_k1": (25, 16, 1, 1, 0), "sc1_137_51": (137, 51, 1, 1, 1),
 }
 

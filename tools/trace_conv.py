@@ -5,11 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from deep_prior_interpolation_amd import ops, _lib
 L = _lib.load()
-shp = (256, 128, 128)
-x = torch.randn((1, 25) + shp, device="cuda")
-w = torch.randn((16, 25, 3, 3, 3), device="cuda") * 0.05
-b = torch.randn(16, device="cuda")
-y = torch.empty((1, 16) + shp, device="cuda")
+CIN, COUT = int(os.environ.get("TR_CIN", 25)), int(os.environ.get("TR_COUT", 16))
+shp = tuple(int(v) for v in os.environ.get("TR_SHAPE", "256,128,128").split(","))
+x = torch.randn((1, CIN) + shp, device="cuda")
+w = torch.randn((COUT, CIN, 3, 3, 3), device="cuda") * 0.05
+b = torch.randn(COUT, device="cuda")
+y = torch.empty((1, COUT) + shp, device="cuda")
 d = ops.make_desc(x, w, 1)
 for _ in range(20):
     ops.raw_conv_fwd(d, x, None, w, b, y)
@@ -21,7 +22,7 @@ for blk in range(4):
     t = [buf[blk * 64 + i] for i in range(64)]
     t0 = t[0]
     print("block slot", blk, "prologue", t[1] - t0, "total", t[41] - t0, "epilogue", t[41] - t[40])
-    for c in range(7):
+    for c in range(min(9, (CIN + 3) // 4)):
         o = 2 + c * 4
         print("   chunk %d: wait-barrier1 %6d  stage_store %6d  barrier2 %6d  mfma-phase %6d" % (
             c, t[o] - (t[o - 1] if c else t[1]), t[o + 1] - t[o], t[o + 2] - t[o + 1], t[o + 3] - t[o + 2]))
@@ -30,7 +31,8 @@ import collections
 big = (ctypes.c_longlong * (8192 * 4))()
 L.dpi_debug_read_blocks.restype = ctypes.c_int
 print("rc", L.dpi_debug_read_blocks(big))
-rows = [(big[i * 4], big[i * 4 + 1], big[i * 4 + 2], big[i * 4 + 3]) for i in range(4096)]
+NB = int(os.environ.get('TR_BLOCKS', 4096))
+rows = [(big[i * 4], big[i * 4 + 1], big[i * 4 + 2], big[i * 4 + 3]) for i in range(NB)]
 t0 = min(r[0] for r in rows)
 print("kernel span us", (max(r[1] for r in rows) - t0) / 100.0, "mean block us", sum(r[1] - r[0] for r in rows) / len(rows) / 100.0)
 percu = collections.defaultdict(list)
