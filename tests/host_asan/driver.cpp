@@ -22,13 +22,13 @@ static dpi_conv_desc desc(int cin, int cout, int D, int H, int W, int k, int kd,
 }
 
 int main() {
-  EXPECT(dpi_version() >= 300, "version %d", dpi_version());
+  EXPECT(dpi_version() >= 301, "version %d", dpi_version());
   EXPECT(dpi_conv_desc_size() == (int)sizeof(dpi_conv_desc), "desc size");
   // a buffer that is big enough for the few bytes host code may legitimately read from "device" pointers: none — host code must never
   // dereference them, ASAN would flag reads of this 16-byte allocation past its end
   std::vector<float> tiny(4, 0.f);
   float* p = tiny.data();
-  long n_desc = 0, n_planned = 0;
+  long n_desc = 0, n_planned = 0, n_split = 0;
   const int channels[][2] = {{64, 4}, {4, 8}, {8, 13}, {25, 16}, {67, 4}, {25, 1}, {25, 25}, {51, 32}, {137, 8}, {105, 64}, {212, 128}, {554, 35},
                              {142, 213}, {1, 1}, {3, 5}, {426, 554}, {64, 25}, {67, 25}, {17, 26}};
   const int shapes[][3] = {{256, 128, 128}, {512, 256, 256}, {128, 64, 64}, {64, 64, 64}, {16, 8, 8}, {4, 4, 4}, {1, 1, 1}, {2, 3, 5}, {9, 17, 33},
@@ -52,6 +52,21 @@ int main() {
             EXPECT(rc == DPI_OK || rc == DPI_E_LAUNCH, "conv_fwd rc %d: %s", rc, dpi_last_error());
             rc = dpi_conv_bwd_data(&d, p, p, p, 1, nullptr);
             EXPECT(rc == DPI_OK || rc == DPI_E_LAUNCH, "conv_bwd_data rc %d: %s", rc, dpi_last_error());
+            // input-channel split (ABI 301): sizing, the split launch planning, a short workspace refused before any launch
+            const size_t fws = dpi_conv_fwd_ws_floats(&d), bws = dpi_conv_bwd_data_ws_floats(&d);
+            EXPECT(fws < ((size_t)1 << 32) && bws < ((size_t)1 << 32), "split workspace %zu / %zu floats", fws, bws);
+            if (fws) {
+              ++n_split;
+              rc = dpi_conv_fwd_ws(&d, p, nullptr, p, p, p, nullptr, p, fws, nullptr);
+              EXPECT(rc == DPI_OK || rc == DPI_E_LAUNCH, "conv_fwd_ws rc %d: %s", rc, dpi_last_error());
+              rc = dpi_conv_fwd_ws(&d, p, nullptr, p, p, p, nullptr, p, fws / 2, nullptr);
+              EXPECT(rc == DPI_E_ARG || rc == DPI_E_WORKSPACE, "short split workspace accepted (rc %d)", rc);
+            }
+            if (bws) {
+              rc = dpi_conv_bwd_data_ws(&d, p, p, p, 1, p, bws, nullptr);
+              EXPECT(rc == DPI_OK || rc == DPI_E_LAUNCH, "conv_bwd_data_ws rc %d: %s", rc, dpi_last_error());
+            }
+            EXPECT(dpi_conv_fwd_ws(&d, p, nullptr, p, p, p, nullptr, nullptr, 16, nullptr) == DPI_E_ARG, "workspace size without a workspace accepted");
             rc = dpi_conv_bwd_weight(&d, p, nullptr, p, p, p, ws, nullptr);
             EXPECT(rc == DPI_OK || rc == DPI_E_LAUNCH, "conv_bwd_weight rc %d: %s", rc, dpi_last_error());
             rc = dpi_conv_bwd_weight(&d, p, nullptr, p, p, p, ws / 2, nullptr);       // short workspace must be refused before any launch
@@ -99,6 +114,7 @@ int main() {
     EXPECT(dpi_upsample2x_bwd_ws_floats(51, 128, 64, 64, 256, 128, 128, 1) > 0, "upsample ws full size");
     EXPECT(dpi_upsample2x_bwd_ws_floats(51, 128, 64, 64, 255, 127, 127, 1) > 0, "upsample ws cropped");
   }
-  std::printf("host sanitizer driver: %ld descriptors, %ld planned launch triples, %d failures\n", n_desc, n_planned, failures);
+  EXPECT(n_split > 0, "no descriptor exercised the input-channel split");
+  std::printf("host sanitizer driver: %ld descriptors, %ld planned launch triples (%ld with an input-channel split), %d failures\n", n_desc, n_planned, n_split, failures);
   return failures ? 1 : 0;
 }
