@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
   }
 
   constexpr int NTG = (TAPS + 3) / 4;                // tap groups of the packed tail
-  const bool tail = TAILPACK && S == 1 && (a.Cin & 3) == 1 && a.Cin > 4;
+  const bool tail = TAILPACK && S == 1 && (a.Cin & 3) == 1 && (a.Cin > 4 || a.Cin == 1);   // Cin = 1: the packed tail is the whole layer
   const int cin_main = a.split_cps ? min(c_lo + a.split_cps, a.Cin) : (tail ? a.Cin - 1 : a.Cin);   // (the split never runs the tap-packed variants)
   int ttoff[TAILPACK ? NTG : 1];
   float wt[TAILPACK ? NTG : 1];
@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
       TRC(5 + (c0 / 4) * 4);
     }
     if constexpr (TAILPACK) {
+      if (tail && cin_main == 0) { load_tail_w(); commit_tail_w(); }     // a single input channel: no main chunk has fetched the packed weights
       if (tail) {
         __syncthreads();
         stage_store<G>(lds, sr, a.chain, a.Cin, cin_main, goff, loff);     // all four slots: channel Cin-1
@@ -955,7 +956,11 @@ bool dpi_mfma_half_tile(const dpi_conv_desc* d, bool flip) {
   const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
   int nr, nh;
   dpi_mfma_variant(d, cout, &nr, &nh);
-  if (nr != 8 || d->kd != 3 || cin <= 8) return false;
+  if (nr != 8 || d->kd != 3) return false;
+  // ONE input channel (backward-data of the 25 -> 1 output layer): the tap-packed tail is the whole layer, 7 MFMAs per 16 x 16
+  // output block instead of 27 with three of four K slices empty (0.31 -> ms measured below)
+  if (cin == 1) return true;
+  if (cin <= 8) return false;
   return flip || ((cin & 3) == 1);
 }
 
@@ -977,7 +982,7 @@ static void launch_variant(const MArgs& a, int nr, int nh, int stride, dim3 grid
     }
     return;
   }
-  const bool tailpack = (a.Cin & 3) == 1 && a.Cin > 4;     // instantiated separately: the packed tail costs ~15 VGPRs
+  const bool tailpack = (a.Cin & 3) == 1 && (a.Cin > 4 || a.Cin == 1);     // instantiated separately: the packed tail costs ~15 VGPRs
   if (nr == 4) {
     if constexpr (KD == 3) {
       if (tailpack) conv_mfma_kernel<KD, 4, 2, FLIP, 1, 3, false, true><<<grid, 256, 0, st>>>(a);
@@ -1131,11 +1136,14 @@ int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const f
     a.ngroups = (int)g.y;
     return dim3(8u * g.y * (unsigned)cdiv((int)g.x, 8), 1, g.z);
   };
-  if (d->stride == 1 && d->kd == 3 && (a.Cin & 3) == 1 && a.Cin > 4) {
-    // staged channel count 4m + 1: full groups in one launch, the one-channel group in a second, column-trimmed one
+  if (d->stride == 1 && d->kd == 3 && (a.Cin & 3) == 1) {
+    // staged channel count 4m + 1: full groups in one launch, the one-channel group in a second, column-trimmed one (a single staged
+    // channel — the swapped 25 -> 1 output layer — is that second launch alone: 2 column tiles instead of 7)
     dim3 gmain(grid.x, grid.y - 1, grid.z), gtail(grid.x, 1, grid.z);
-    dim3 gm = xcd_grid(gmain);
-    conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<gm, 256, bw_extra_lds(), st>>>(a);
+    if (grid.y > 1) {
+      dim3 gm = xcd_grid(gmain);
+      conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<gm, 256, bw_extra_lds(), st>>>(a);
+    }
     a.y0 = (int)grid.y - 1;
     dim3 gt = xcd_grid(gtail);
     conv_bwd_weight_mfma_kernel<3, 1, 8, 2, 1><<<gt, 256, 0, st>>>(a);

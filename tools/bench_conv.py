@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--bf16-debug", type=int, default=0)
     ap.add_argument("--bw-want", type=int, default=0, help="backward-weight plan: workgroups aimed at (dpi_set_bw_tuning)")
     ap.add_argument("--bw-xcd", type=int, default=-1, help="backward-weight plan: XCD-aware workgroup order 0/1")
+    ap.add_argument("--accumulate", action="store_true", help="backward-data adds into dx (gradient fan-in)")
     ap.add_argument("--q4", type=int, default=-1, help="4x4x1-MFMA few-output-channel kernel: 0 off, 1 where it pays, 2 forced (dpi_set_q4)")
     ap.add_argument("--q4-debug", type=int, default=0, help="phase-skipping bits of the q4 kernel (timing experiments, wrong results)")
     ap.add_argument("--q4-ck", type=int, default=-1, help="... its input channels per chunk (2 or 4)")
@@ -73,7 +74,7 @@ def main():
         vo = osh[0] * osh[1] * osh[2]
         flop = 2.0 * cin * k ** 3 * cout * vo
         byt = 4.0 * (x.numel() + y.numel())
-        fns = {"fwd": lambda: ops.raw_conv_fwd(d, x, None, w, b, y), "bwd_data": lambda: ops.raw_conv_bwd_data(d, dy, w, dx),
+        fns = {"fwd": lambda: ops.raw_conv_fwd(d, x, None, w, b, y), "bwd_data": lambda: ops.raw_conv_bwd_data(d, dy, w, dx, accumulate=a.accumulate),
                "bwd_weight": lambda: ops.raw_conv_bwd_weight(d, x, None, dy, dw)}
         for which in a.which:
             fn = fns[which]
