@@ -448,8 +448,16 @@ struct BwMArgs {
 
 // TC != 0: the launch covers a final group that holds only TC real channels (Cin = 4m + 1: TC = 1) and computes just their
 // (channel, tap) column tiles: 2 instead of 7 — the padded channels' 80 columns are not multiplied at all.
-template <int KD, int S, int NR, int NH, int TC = 0>
-__global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
+template <int KD, int S, int NR, int NH>
+struct BwLds {
+  using G = Geo<KD, NR, NH, S>;
+  static constexpr int NTQ0 = (4 * KD * 9 + 15) / 16;
+  static constexpr int LDSF = 4 * G::CS > 4 * NTQ0 * 256 ? 4 * G::CS : 4 * NTQ0 * 256;   // halo tile of 4 channels / the cross-wave reduction
+  static constexpr int DYRS = 4 * (4 * NH) + 4;            // row stride of the dY transpose buffer: = 4 (mod 32) -> 2-pass reads
+};
+
+template <int KD, int S, int NR, int NH, int TC>
+__device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a, float* __restrict__ lds, float* __restrict__ dyl_all) {
 #ifdef DPI_TRACE
   const int trc = (blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 4) ? (int)blockIdx.x : -1;
   int trn = 0;
@@ -464,16 +472,13 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
   constexpr int NQ = (TC ? TC : 4) * TAPS;    // (channel, tap) columns of this block: 108 (3-D) / 36 (2-D); tail: TC x TAPS
   constexpr int NTQ = (NQ + 15) / 16;         // MFMA column tiles: 7 (96 % full) / 3 (75 %)
   constexpr int KS = 4 * NH;                  // k-steps (4 voxels each) per output row
-  constexpr int LDSF = 4 * G::CS > 4 * NTQ * 256 ? 4 * G::CS : 4 * NTQ * 256;
   constexpr int JP = KS / 4;                  // float4 pieces of a dY row each lane fetches (16 channels x KS pieces / 64 lanes)
-  constexpr int DYRS = 4 * KS + 4;            // row stride of the dY transpose buffer: = 4 (mod 32) -> 2-pass reads
-  __shared__ __attribute__((aligned(16))) float lds[LDSF];
-  __shared__ __attribute__((aligned(16))) float dyl[4][16 * DYRS];
+  constexpr int DYRS = BwLds<KD, S, NR, NH>::DYRS;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lk = lane >> 4, lj = lane & 15;
   const int wch = lane >> 2, wp = lane & 3;   // dY fetch mapping: channel, float4 piece
-  float* __restrict__ dyw = dyl[wid];
+  float* __restrict__ dyw = dyl_all + wid * 16 * DYRS;
   int chunk = blockIdx.x, group = blockIdx.y;
   if (a.ngroups > 0) {
     const int L = blockIdx.x, r = L >> 3;
@@ -621,6 +626,26 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
       else a.ws[(((size_t)chunk * a.Cout + co) * a.Cin + ci) * TAPS + tap] = sum;
     }
   }
+}
+
+template <int KD, int S, int NR, int NH, int TC = 0>
+__global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
+  using L = BwLds<KD, S, NR, NH>;
+  __shared__ __attribute__((aligned(16))) float lds[L::LDSF];
+  __shared__ __attribute__((aligned(16))) float dyl[4 * 16 * L::DYRS];
+  conv_bwd_weight_mfma_body<KD, S, NR, NH, TC>(a, lds, dyl);
+}
+
+// Staged channel count 4m + 1 in ONE launch: the workgroups of the last group (blockIdx.y = gridDim.y - 1) run the column-trimmed
+// body (one real channel: 2 MFMA column tiles instead of 7) next to the full groups, instead of a second launch behind them whose
+// 1/25 of the work took 11 % of the time (25 -> 16 at 256x128x128: 0.94 + 0.11 ms).
+template <int KD, int S, int NR, int NH>
+__global__ __launch_bounds__(256) void conv_bwd_weight_mfma_merged_kernel(BwMArgs a) {
+  using L = BwLds<KD, S, NR, NH>;
+  __shared__ __attribute__((aligned(16))) float lds[L::LDSF];
+  __shared__ __attribute__((aligned(16))) float dyl[4 * 16 * L::DYRS];
+  if (blockIdx.y + 1 == gridDim.y) conv_bwd_weight_mfma_body<KD, S, NR, NH, 1>(a, lds, dyl);
+  else conv_bwd_weight_mfma_body<KD, S, NR, NH, 0>(a, lds, dyl);
 }
 
 // ---------------------------------------------------------------- backward-weight, few output channels ---------------
@@ -1139,14 +1164,20 @@ int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const f
   if (d->stride == 1 && d->kd == 3 && (a.Cin & 3) == 1) {
     // staged channel count 4m + 1: full groups in one launch, the one-channel group in a second, column-trimmed one (a single staged
     // channel — the swapped 25 -> 1 output layer — is that second launch alone: 2 column tiles instead of 7)
-    dim3 gmain(grid.x, grid.y - 1, grid.z), gtail(grid.x, 1, grid.z);
-    if (grid.y > 1) {
-      dim3 gm = xcd_grid(gmain);
-      conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<gm, 256, bw_extra_lds(), st>>>(a);
+    static const bool merged = getenv("DPI_BW_TWO_LAUNCHES") == nullptr;
+    if (merged && grid.y > 1 && !g_bw_xcd_order) {
+      a.ngroups = 0;
+      conv_bwd_weight_mfma_merged_kernel<3, 1, 8, 2><<<grid, 256, bw_extra_lds(), st>>>(a);
+    } else {
+      dim3 gmain(grid.x, grid.y - 1, grid.z), gtail(grid.x, 1, grid.z);
+      if (grid.y > 1) {
+        dim3 gm = xcd_grid(gmain);
+        conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<gm, 256, bw_extra_lds(), st>>>(a);
+      }
+      a.y0 = (int)grid.y - 1;
+      dim3 gt = xcd_grid(gtail);
+      conv_bwd_weight_mfma_kernel<3, 1, 8, 2, 1><<<gt, 256, 0, st>>>(a);
     }
-    a.y0 = (int)grid.y - 1;
-    dim3 gt = xcd_grid(gtail);
-    conv_bwd_weight_mfma_kernel<3, 1, 8, 2, 1><<<gt, 256, 0, st>>>(a);
   } else if (d->stride == 1) {
     dim3 g = xcd_grid(grid);
     if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 1, 8, 2><<<g, 256, bw_extra_lds(), st>>>(a);
