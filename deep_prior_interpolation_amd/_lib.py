@@ -55,6 +55,8 @@ SIGNATURES = {
     "dpi_conv_fwd_ws": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "dpi_conv_bwd_data_ws": (_I, [_DESC, _P, _P, _P, _I, _P, _Z, _P]),
     "dpi_set_splitk": (None, [_I]),
+    "dpi_conv_bwd_data_dual": (_I, [_DESC, _P, _P, _DESC, _P, _P, _P, _I, _P, _Z, _P]),
+    "dpi_set_dual_bwd_data": (None, [_I]),
     "dpi_conv_bwd_weight_ws_floats": (_Z, [_DESC]),
     "dpi_conv_bwd_weight": (_I, [_DESC, _P, _P, _P, _P, _P, _Z, _P]),
     "dpi_set_mfma_min_cout": (None, [_I]),

@@ -22,6 +22,8 @@ int dpi_check_conv_desc(const dpi_conv_desc* d);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
+// optional second input of the MFMA stencil kernel (conv_mfma.hip): y += W2 * x2 through a 1x1(x1) kernel at the output positions
+struct MfmaSecond { const float* x2; const float* w2; int C2; long w2_co_stride, w2_c_stride; };
 
 // ---- per-channel load transform ("chain"): T(x) = qs*act(ps*x+pb)+qb -----------------------------
 struct Chain {

@@ -442,8 +442,9 @@ int dpi_check_conv_desc(const dpi_conv_desc* d) {
 
 // MFMA stencil path (conv_mfma.hip): k = 3, stride 1, enough output channels to fill a 16-row MFMA tile
 int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
-                      double* partials, bool flip, int accumulate, float* ws, size_t ws_floats, hipStream_t st);
+                      double* partials, bool flip, int accumulate, float* ws, size_t ws_floats, hipStream_t st, const MfmaSecond* sec = nullptr);
 size_t dpi_conv_mfma_ws_floats(const dpi_conv_desc* d, bool flip);
+bool dpi_conv_mfma_second_ok(const dpi_conv_desc* d, bool flip, int C2, bool have_ws);
 void dpi_conv_pw_mfma_plan(size_t V, int cout, int* vox_per_block, int* mt);
 bool dpi_conv_fewco_usable(const dpi_conv_desc* d);
 bool dpi_conv_q4_usable(const dpi_conv_desc* d, bool flip);
@@ -567,6 +568,27 @@ extern "C" int dpi_conv_fwd(const dpi_conv_desc* d, const float* x, const float*
 extern "C" int dpi_conv_bwd_data(const dpi_conv_desc* d, const float* dy, const float* w, float* dx,
                                  int accumulate, void* stream) {
   return dpi_conv_bwd_data_ws(d, dy, w, dx, accumulate, nullptr, 0, stream);
+}
+
+// dx (+)= conv_transpose(dy3, w3) + conv_transpose(dy1, w1) for a 3x3(x3) layer d3 and a 1x1(x1) layer d1 reading the same tensor
+static int g_dual = getenv("DPI_NO_DUAL") ? 0 : 1;
+extern "C" void dpi_set_dual_bwd_data(int on) { g_dual = on; }
+extern "C" int dpi_conv_bwd_data_dual(const dpi_conv_desc* d3, const float* dy3, const float* w3, const dpi_conv_desc* d1, const float* dy1,
+                                      const float* w1, float* dx, int accumulate, float* ws, size_t ws_floats, void* stream) {
+  if (int e = check_desc(d3)) return e;
+  if (int e = check_desc(d1)) return e;
+  DPI_REQUIRE(dy3 && w3 && dy1 && w1 && dx, "conv_bwd_data_dual: null tensor");
+  DPI_REQUIRE(ws || ws_floats == 0, "conv_bwd_data_dual: workspace size without a workspace");
+  DPI_REQUIRE(d3->k == 3 && d1->k == 1 && d3->stride == 1 && d1->stride == 1, "conv_bwd_data_dual: needs a 3x3(x3) and a 1x1(x1) stride-1 layer");
+  DPI_REQUIRE(d3->Cin == d1->Cin && d3->D == d1->D && d3->H == d1->H && d3->W == d1->W, "conv_bwd_data_dual: the two layers read different tensors");
+  hipStream_t st = (hipStream_t)stream;
+  if (g_dual && takes_mfma_path(d3, true) && dpi_conv_mfma_second_ok(d3, true, d1->Cout, ws != nullptr)) {
+    // W2[ci][co1] = w1[co1][ci]: rows of this launch are the layers' INPUT channels
+    const MfmaSecond sec{dy1, w1, d1->Cout, 1, (long)d1->Cin};
+    return dpi_conv_mfma_run(d3, dy3, nullptr, w3, nullptr, dx, nullptr, true, accumulate, nullptr, 0, st, &sec);
+  }
+  if (int e = conv_run(d1, dy1, nullptr, w1, nullptr, dx, nullptr, true, accumulate, nullptr, 0, st)) return e;
+  return conv_run(d3, dy3, nullptr, w3, nullptr, dx, nullptr, true, 1, ws, ws_floats, st);
 }
 
 extern "C" int dpi_conv_bwd_data_ws(const dpi_conv_desc* d, const float* dy, const float* w, float* dx,

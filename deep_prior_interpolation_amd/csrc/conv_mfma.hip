@@ -39,6 +39,13 @@ struct MArgs {
   // [z * split_cps, (z + 1) * split_cps) only and writes its partial result to y + z * Cout * Vo (y = the workspace; no bias,
   // no statistics, no fan-in: splitk_reduce_kernel adds those).  0: blockIdx.z = 0 covers every channel.
   int split_cps;
+  // second input through a 1x1(x1) kernel at the OUTPUT positions (x2 != nullptr): y += W2 * x2, x2 [C2][Do][Ho][Wo],
+  // W2[co][c] = w2[co * w2_co_stride + c * w2_c_stride].  Backward-data of a 3x3x3 layer and a 1x1x1 layer that read the same
+  // tensor (Block3d.conv1 + shortcut, ResPath3d.conv3x3 + conv1x1) as ONE pass over dx instead of write + read-modify-write.
+  const float* __restrict__ x2;
+  const float* __restrict__ w2;
+  int C2;
+  long w2_co_stride, w2_c_stride;
 };
 
 // Tile geometry.  A wave owns NR output rows x NH 16-voxel column blocks; the 4 waves of a workgroup own
@@ -363,6 +370,40 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
 #pragma unroll
             for (int h = 0; h < NH; ++h)
               acc[hr * NH + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[g], tb[h][g], acc[hr * NH + h], 0, 0, 0);
+        }
+      }
+    }
+    if constexpr (FLIP && !PERSIST) if (a.x2 != nullptr) {     // (only backward-data launches of the non-persistent variants carry a second input)
+      // 1x1x1 contribution: D[co][vox] += A[co][c 4] * B[c 4][vox] per 4-channel group of x2, B straight from global memory in MFMA
+      // layout (lane = (c = lk, vox = lj): 64 B per channel and row segment; each value is used by this wave only, so LDS would
+      // add nothing).  ONE buffer over all of x2: channels >= C2 and out-of-volume voxels are out of range -> 0.
+      const __amdgpu_buffer_rsrc_t r2 = dpi_buffer(a.x2, (size_t)a.C2 * Vo * sizeof(float));
+      int voff[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
+        voff[t] = (od < Do && oh < Ho && ow < Wo) ? (od * Ho + oh) * Wo + ow : -1;
+      }
+      const int nk2 = (a.C2 + 3) >> 2;
+      auto load2 = [&](float (&b)[NT], float& wv, int kc) {
+        const int c = kc * 4 + lk;
+        const bool ok = c < a.C2 && co_w < a.Cout;
+        const float wraw = a.w2[(ok ? co_w : 0) * a.w2_co_stride + (ok ? c : 0) * a.w2_c_stride];
+        wv = ok ? wraw : 0.f;
+        const int cbase = c * (int)Vo;                      // host guarantees C2 * Vo * 4 < 2^31 (+ one channel group of slack)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = dpi_buffer_load(r2, voff[t] >= 0 ? (cbase + voff[t]) * 4 : -4);
+      };
+      float b0[NT], b1[NT], w0v, w1v;
+      load2(b0, w0v, 0);
+      for (int kc = 0; kc < nk2; kc += 2) {                 // two groups per trip: the next group's loads are in flight behind this one's MFMAs
+        if (kc + 1 < nk2) load2(b1, w1v, kc + 1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0v, b0[t], acc[t], 0, 0, 0);
+        if (kc + 1 < nk2) {
+          if (kc + 2 < nk2) load2(b0, w0v, kc + 2);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v, b1[t], acc[t], 0, 0, 0);
         }
       }
     }
@@ -1066,18 +1107,30 @@ size_t dpi_conv_mfma_ws_floats(const dpi_conv_desc* d, bool flip) {
   return (size_t)ns * (flip ? d->Cin : d->Cout) * Do * Ho * Wo;
 }
 
+// whether dpi_conv_mfma_run can add a 1x1x1 second input of C2 channels in the same pass (MfmaSecond)
+bool dpi_conv_mfma_second_ok(const dpi_conv_desc* d, bool flip, int C2, bool have_ws) {
+  int Do, Ho, Wo;
+  dpi_conv_out_dims(d, &Do, &Ho, &Wo);
+  if (!flip || d->stride != 1 || C2 < 1 || ((size_t)C2 + 4) * Do * Ho * Wo * sizeof(float) >= ((size_t)1 << 31)) return false;
+  int nr, nh;
+  dpi_mfma_variant(d, d->Cin, &nr, &nh);
+  if (nr == 8 && !dpi_mfma_half_tile(d, flip) && d->Cout > 8) return false;   // the persistent variant is compiled without it
+  return !(have_ws && dpi_mfma_splitk(d, flip) > 1);        // the split launches write partial outputs: the pair stays two launches there
+}
+
 int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
-                      double* partials, bool flip, int accumulate, float* ws, size_t ws_floats, hipStream_t st) {
+                      double* partials, bool flip, int accumulate, float* ws, size_t ws_floats, hipStream_t st, const MfmaSecond* sec) {
   const int taps = d->kd * 9;
   const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
   const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
-  MArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, accumulate, 0};
+  MArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, accumulate, 0, nullptr, nullptr, 0, 0, 0};
   int nr, nh;
   dpi_mfma_variant(d, cout, &nr, &nh);
   if (dpi_mfma_half_tile(d, flip)) nr = 4;
   const int ntiles = dpi_mfma_tiles(d, nr, nh, &a.ntd, &a.nth, &a.ntw);
   dim3 grid(ntiles, cdiv(cout, 16));
-  const int nsplit = ws ? dpi_mfma_splitk(d, flip) : 1;
+  if (sec) { a.x2 = sec->x2; a.w2 = sec->w2; a.C2 = sec->C2; a.w2_co_stride = sec->w2_co_stride; a.w2_c_stride = sec->w2_c_stride; }
+  const int nsplit = (ws && !sec) ? dpi_mfma_splitk(d, flip) : 1;
   if (nsplit > 1) {
     int Do, Ho, Wo;
     dpi_conv_out_dims(d, &Do, &Ho, &Wo);

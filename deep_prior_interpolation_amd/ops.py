@@ -166,6 +166,20 @@ def raw_conv_bwd_data(d, dy, w, dx, accumulate=False):
                                                                     ptr(ws), n, stream()), "dpi_conv_bwd_data"))
 
 
+def raw_conv_bwd_data_dual(d3, dy3, w3, d1, dy1, w1, dx, accumulate=False):
+    """dx (+)= conv_transpose(dy3, w3) + conv_transpose(dy1, w1): a 3x3(x3) layer and a 1x1(x1) layer that read the same tensor
+    (Block3d.conv1 + shortcut, ResPath3d.conv3x3 + conv1x1).  One pass over dx where the MFMA stencil kernel serves the 3x3(x3) layer
+    (the 1x1x1 term is a few extra MFMAs on operands read straight from dy1), two launches (write, then add) otherwise."""
+    L = _lib.load()
+    n = L.dpi_conv_bwd_data_ws_floats(C.byref(d3))
+    ws = _conv_ws(n, dy3)
+
+    def launch():
+        check(L.dpi_conv_bwd_data_dual(C.byref(d3), ptr(dy3), ptr(w3), C.byref(d1), ptr(dy1), ptr(w1), ptr(dx), int(accumulate),
+                                       ptr(ws), n, stream()), "dpi_conv_bwd_data_dual")
+    _timed("conv_bwd_data", d3, launch)
+
+
 # ------------------------------------------------------------------------------------------------
 # side stream for weight gradients: dW of a layer depends only on (x, dy) and nothing downstream depends on it before the
 # optimiser step, so it runs concurrently with the backward-data / BatchNorm-backward chain.  At the coarse levels of the
@@ -600,8 +614,7 @@ class Block3dFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            raw_conv_bwd_data(dsc, dS, ws, dx)
-            raw_conv_bwd_data(d1, dR[:, s1], w1, dx, accumulate=True)
+            raw_conv_bwd_data_dual(d1, dR[:, s1], w1, dsc, dS, ws, dx)
         join_weight_grads()
         z = _zeros_like_or_none      # conv biases feed a BatchNorm: analytically zero gradient
         return (dx, None, None, dw1, z(b1), dg1, de1, dw2, z(b2), dg2, de2, dw3, z(b3), dg3, de3, dws, z(bs), dgs, des,
@@ -663,8 +676,7 @@ class ResPath3dFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            raw_conv_bwd_data(d1, dr1, w1, dx)
-            raw_conv_bwd_data(d3, dr3, w3, dx, accumulate=True)
+            raw_conv_bwd_data_dual(d3, dr3, w3, d1, dr1, w1, dx)
         join_weight_grads()
         z = _zeros_like_or_none
         return dx, None, None, dw3, z(b3), dg3, de3, dw1, z(b1), dg1, de1, dgB, deB
@@ -740,8 +752,7 @@ class SkipJoinFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            raw_conv_bwd_data(d1, dr1, w1, dx)
-            raw_conv_bwd_data(d3, dr3, w3, dx, accumulate=True)
+            raw_conv_bwd_data_dual(d3, dr3, w3, d1, dr1, w1, dx)
         join_weight_grads()
         z = _zeros_like_or_none
         return dx, ddeep, None, None, None, dw3, z(b3), dg3, de3, dw1, z(b1), dg1, de1, dgB, deB

@@ -105,6 +105,16 @@ int dpi_conv_bwd_data_ws(const dpi_conv_desc* d, const float* dy, const float* w
                          int accumulate, float* ws, size_t ws_floats, void* stream);
 /* 0 switches the input-channel split off (A/B testing; default on, DPI_SPLITK=0 in the environment does the same) */
 void dpi_set_splitk(int on);
+/* dx (+)= conv_transpose(dy3, w3) + conv_transpose(dy1, w1) for a 3x3(x3) stride-1 layer d3 and a 1x1(x1) layer d1 that read the SAME
+ * tensor (equal Cin, D, H, W): Block3d.conv1 + shortcut (mulresunet.py:72-96) and ResPath3d.conv3x3 + conv1x1 (mulresunet.py:99-113),
+ * whose input gradient is the sum of the two transposed convolutions.  Where the fp32-MFMA stencil kernel serves d3, the 1x1x1 term is
+ * accumulated in the same pass (dx written once instead of written by one launch and read-modified-written by the next); every other
+ * case runs the two launches.  ws / ws_floats: dpi_conv_bwd_data_ws_floats(d3) (may be NULL / 0). */
+int dpi_conv_bwd_data_dual(const dpi_conv_desc* d3, const float* dy3, const float* w3,
+                           const dpi_conv_desc* d1, const float* dy1, const float* w1,
+                           float* dx, int accumulate, float* ws, size_t ws_floats, void* stream);
+/* 0: dpi_conv_bwd_data_dual always runs two launches (A/B testing; DPI_NO_DUAL in the environment does the same) */
+void dpi_set_dual_bwd_data(int on);
 /* dw[Cout][Cin][kd][k][k] = sum_p dy[co][p] * T(x)[ci][p*stride + tap - pad].
  * workspace: float[dpi_conv_bwd_weight_ws_floats(d)].  */
 size_t dpi_conv_bwd_weight_ws_floats(const dpi_conv_desc* d);

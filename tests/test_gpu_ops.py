@@ -225,6 +225,58 @@ def test_conv_input_channel_split_vs_oracle(ops, cin, cout, shape, stride):
     assert torch.equal(y3, y0)
 
 
+DUAL_CASES = [(67, 4, 25, (12, 16, 40)), (25, 16, 16, (8, 16, 32)), (25, 16, 16, (33, 31, 50)), (137, 8, 51, (6, 10, 18)),
+              (51, 32, 32, (16, 16, 64)), (8, 13, 9, (8, 16, 32)), (105, 64, 64, (4, 6, 10)), (13, 9, 7, (1, 20, 24)),
+              (67, 4, 25, (40, 48, 64)), (554, 35, 212, (4, 8, 16))]
+
+
+@pytest.mark.parametrize("cin,c3,c1,shape", DUAL_CASES)
+def test_conv_bwd_data_dual_vs_oracle(ops, cin, c3, c1, shape):
+    """dpi_conv_bwd_data_dual: input gradient of a 3x3(x3) layer and a 1x1(x1) layer reading the same tensor (Block3d conv1 + shortcut,
+    ResPath3d) in one pass — fused into the MFMA stencil kernel's epilogue where that kernel serves the 3x3(x3) layer, two launches
+    elsewhere (few-channel 4x4x1 kernel, input-channel split, 2-D big tiles): against the fp64 oracle, with and without fan-in, and
+    against the two separate launches."""
+    import ctypes as C
+    from deep_prior_interpolation_amd import _lib
+    L = _lib.load()
+    gen = torch.Generator().manual_seed(cin + 31 * c3 + c1)
+    kd = 1 if shape[0] == 1 else 3
+    w3 = torch.randn((c3, cin, kd, 3, 3), generator=gen) * (1.0 / np.sqrt(c3 * 9 * kd))
+    w1 = torch.randn((c1, cin, 1, 1, 1), generator=gen) * (1.0 / np.sqrt(c1))
+    dy3 = torch.randn((1, c3) + shape, generator=gen)
+    dy1 = torch.randn((1, c1) + shape, generator=gen)
+    xr = torch.zeros((1, cin) + shape, dtype=torch.float64, requires_grad=True)
+    if kd == 3:
+        y = O.conv_nd(xr, w3.double(), None, 1), O.conv_nd(xr, w1.double(), None, 1)
+    else:
+        y = O.conv_nd(xr[:, :, 0], w3[:, :, 0].double(), None, 1)[:, :, None], O.conv_nd(xr[:, :, 0], w1[:, :, 0].double(), None, 1)[:, :, None]
+    (y[0] * dy3.double()).sum().backward(retain_graph=True)
+    (y[1] * dy1.double()).sum().backward()
+    ref = xr.grad
+    w3g, w1g, dy3g, dy1g = w3.to(DEV), w1.to(DEV), dy3.to(DEV), dy1.to(DEV)
+    xg = torch.empty((1, cin) + shape, device=DEV)
+    d3 = ops.make_desc(xg, w3g if kd == 3 else w3g[:, :, 0], 1)
+    d1 = ops.make_desc(xg, w1g if kd == 3 else w1g[:, :, 0], 1)
+    dx = torch.full(xg.shape, float("nan"), device=DEV)
+    ops.raw_conv_bwd_data_dual(d3, dy3g, w3g, d1, dy1g, w1g, dx)
+    assert rel(dx, ref) < 2e-6
+    base = torch.randn(xg.shape, generator=gen)
+    dxa = base.to(DEV).clone()
+    ops.raw_conv_bwd_data_dual(d3, dy3g, w3g, d1, dy1g, w1g, dxa, accumulate=True)
+    assert rel(dxa, ref + base.double()) < 2e-6
+    dx2 = torch.full(xg.shape, float("nan"), device=DEV)
+    L.dpi_set_dual_bwd_data(0)
+    try:
+        ops.raw_conv_bwd_data_dual(d3, dy3g, w3g, d1, dy1g, w1g, dx2)
+    finally:
+        L.dpi_set_dual_bwd_data(1)
+    assert rel(dx2, ref) < 2e-6 and rel(dx, dx2) < 2e-6
+    dx3 = torch.empty_like(dx)
+    ops.raw_conv_bwd_data(d1, dy1g, w1g, dx3)
+    ops.raw_conv_bwd_data(d3, dy3g, w3g, dx3, accumulate=True)
+    assert torch.equal(dx2, dx3)
+
+
 @pytest.mark.parametrize("name", ["bn3d", "bn2d"])
 def test_bn_golden(golden, ops, name):
     g = golden("ops")[name]

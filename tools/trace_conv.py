@@ -11,7 +11,9 @@ x = torch.randn((1, CIN) + shp, device="cuda")
 w = torch.randn((COUT, CIN, 3, 3, 3), device="cuda") * 0.05
 b = torch.randn(COUT, device="cuda")
 y = torch.empty((1, COUT) + shp, device="cuda")
-d = ops.make_desc(x, w, 1)
+STRIDE = int(os.environ.get("TR_STRIDE", 1))
+d = ops.make_desc(x, w, STRIDE)
+y = torch.empty((1, COUT) + ops.desc_out_dims(d), device="cuda")
 for _ in range(20):
     ops.raw_conv_fwd(d, x, None, w, b, y)
 torch.cuda.synchronize()
