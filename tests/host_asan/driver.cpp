@@ -67,6 +67,13 @@ int main() {
               EXPECT(rc == DPI_OK || rc == DPI_E_LAUNCH, "conv_bwd_data_ws rc %d: %s", rc, dpi_last_error());
             }
             EXPECT(dpi_conv_fwd_ws(&d, p, nullptr, p, p, p, nullptr, nullptr, 16, nullptr) == DPI_E_ARG, "workspace size without a workspace accepted");
+            if (k == 3 && stride == 1) {      // the 3x3(x3) + 1x1(x1) pair that reads one tensor: fused or two launches, both plan here
+              dpi_conv_desc d1 = desc(ch[0], ch[1] + 9, sh[0], sh[1], sh[2], 1, 1, 1, prec);
+              rc = dpi_conv_bwd_data_dual(&d, p, p, &d1, p, p, p, 0, bws ? p : nullptr, bws, nullptr);
+              EXPECT(rc == DPI_OK || rc == DPI_E_LAUNCH, "conv_bwd_data_dual rc %d: %s", rc, dpi_last_error());
+              dpi_conv_desc dbad = desc(ch[0] + 1, ch[1], sh[0], sh[1], sh[2], 1, 1, 1, prec);
+              EXPECT(dpi_conv_bwd_data_dual(&d, p, p, &dbad, p, p, p, 0, nullptr, 0, nullptr) == DPI_E_ARG, "dual: mismatched layers accepted");
+            }
             rc = dpi_conv_bwd_weight(&d, p, nullptr, p, p, p, ws, nullptr);
             EXPECT(rc == DPI_OK || rc == DPI_E_LAUNCH, "conv_bwd_weight rc %d: %s", rc, dpi_last_error());
             rc = dpi_conv_bwd_weight(&d, p, nullptr, p, p, p, ws / 2, nullptr);       // short workspace must be refused before any launch
