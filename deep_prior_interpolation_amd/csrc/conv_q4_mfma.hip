@@ -307,11 +307,16 @@ __device__ __forceinline__ int qi_pos(int col) {                     // float of
   return (4 * g + (j ^ ((g >> 1) & 3))) * 4;
 }
 
-template <int R, int NB, bool FLIP, bool AL>
+// KHP (ONE output channel, forward: the 25 -> 1 output layer): the 4 MFMA rows hold the three kh taps of that channel instead of four
+// channels (three of which do not exist).  An input row then feeds its three output rows with ONE MFMA per (kw, channel) — accumulator
+// of INPUT row q, component kh = the partial sum of output row q - kh — and the epilogue adds the three shifted components:
+// 360 MFMAs per chunk and wave instead of 864, rows 75 % instead of 25 % full.
+template <int R, int NB, bool FLIP, bool AL, bool KHP = false>
 __global__ __launch_bounds__(256, 2) void conv_q4i_mfma_kernel(QArgs a) {
+  static_assert(!KHP || (NB == 1 && !FLIP), "kh-packed rows: one output channel, forward only");
   using G = QiGeo<R>;
   constexpr int TAPS = 27;
-  constexpr int NWT = TAPS * NB * 16;             // weight table of one chunk: [tap][s][i][ci]
+  constexpr int NWT = KHP ? 9 * 16 : TAPS * NB * 16;   // weight table of one chunk: [tap][s][i][ci]  (KHP: [kd][kw][i = kh][ci])
   constexpr int WE = (NWT + 255) / 256;
   __shared__ __attribute__((aligned(16))) float lds[G::TILE];
   __shared__ __attribute__((aligned(16))) float wl[NWT];
@@ -384,6 +389,11 @@ __global__ __launch_bounds__(256, 2) void conv_q4i_mfma_kernel(QArgs a) {
   };
   (void)swz;
   auto wt_index = [&](int t, int c0, bool& ok) {      // t = ((tap * NB + s) * 4 + i) * 4 + c
+    if constexpr (KHP) {                              // t = ((kd * 3 + kw) * 4 + kh) * 4 + c, output channel 0
+      const int c = t & 3, kh = (t >> 2) & 3, kw = (t >> 4) % 3, kd = min((t >> 4) / 3, 2), ci = c0 + c;
+      ok = t < NWT && kh < 3 && ci < a.Cin;
+      return (ok ? ci : 0) * a.w_in_stride + kd * 9 + (ok ? kh : 0) * 3 + kw;
+    }
     const int c = t & 3, i = (t >> 2) & 3, s = (t >> 4) % NB, tap = (t >> 4) / NB;
     const int co = 4 * s + i, ci = c0 + c;
     ok = t < NWT && co < a.Cout && ci < a.Cin;
@@ -412,6 +422,10 @@ __global__ __launch_bounds__(256, 2) void conv_q4i_mfma_kernel(QArgs a) {
   for (int hr = 0; hr < R; ++hr)
 #pragma unroll
     for (int s = 0; s < NB; ++s) acc[hr][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // KHP: per INPUT row, component kh; two partial accumulators per row (a dependent 4x4x1 MFMA needs ~15 clk, an independent one 8.5)
+  f32x4 accp[KHP ? G::IH : 1][2];
+#pragma unroll
+  for (int q = 0; q < (KHP ? G::IH : 1); ++q) { accp[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; accp[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
   f32x4 sr[G::E][4];
   float wreg[WE];
@@ -433,10 +447,15 @@ __global__ __launch_bounds__(256, 2) void conv_q4i_mfma_kernel(QArgs a) {
       for (int kw = 0; kw < 3; ++kw) xv[kw] = *reinterpret_cast<const f32x4*>(lds + xoff[kw] + kd * G::DS + ir * G::RS);
     };
     auto load_w = [&](f32x4 (&wr)[9][NB], int kd) {
+      if constexpr (KHP) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+        for (int kw = 0; kw < 3; ++kw) wr[kw][0] = wl4[(kd * 3 + kw) * 4];     // this lane's row kh = lane & 3, four channels
+      } else {
 #pragma unroll
-        for (int s = 0; s < NB; ++s) wr[t][s] = wl4[((kd * 9 + t) * NB + s) * 4];
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int s = 0; s < NB; ++s) wr[t][s] = wl4[((kd * 9 + t) * NB + s) * 4];
+      }
     };
     f32x4 wr[9][NB], xv[3], xn[3];
     load_w(wr, 0);
@@ -454,6 +473,14 @@ __global__ __launch_bounds__(256, 2) void conv_q4i_mfma_kernel(QArgs a) {
         if (ir + 1 < G::IH) load_x(xn, kd, ir + 1);
         else if (kd + 1 < 3) load_x(xn, kd + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (KHP) {
+          // 12 dependent MFMAs on one accumulator would wait ~15 clk each: two partial accumulators per row, merged below
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              accp[ir][c & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[kw][0][c], xv[kw][c], accp[ir][c & 1], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
@@ -467,6 +494,7 @@ __global__ __launch_bounds__(256, 2) void conv_q4i_mfma_kernel(QArgs a) {
                   acc[hr][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[kh * 3 + kw][s][c], xv[kw][c], acc[hr][s], 0, 0, 0);
               }
             }
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) xv[kw] = xn[kw];
@@ -475,6 +503,11 @@ __global__ __launch_bounds__(256, 2) void conv_q4i_mfma_kernel(QArgs a) {
     }
   }
 
+  if constexpr (KHP) {                                // output row hr = input rows hr, hr + 1, hr + 2 through taps kh = 0, 1, 2
+#pragma unroll
+    for (int hr = 0; hr < R; ++hr)
+      acc[hr][0][0] = ((accp[hr][0][0] + accp[hr][1][0]) + (accp[hr + 1][0][1] + accp[hr + 1][1][1])) + (accp[hr + 2][0][2] + accp[hr + 2][1][2]);
+  }
   const bool col_ok = od < Do && ow < Wo;
 #pragma unroll
   for (int s = 0; s < NB; ++s)
@@ -528,6 +561,7 @@ __global__ __launch_bounds__(256, 2) void conv_q4i_mfma_kernel(QArgs a) {
 static int g_q4 = 1;          // dpi_set_q4: 0 off, 1 where it pays (below), 2 every shape it can run (tests)
 static int g_q4_ck = 0;        // 0: by shape (q4_launch), 2 / 4: force the planar / the channel-interleaved variant
 static int g_q4_dbg = 0;
+static int g_q4_khp = getenv("DPI_NO_KHP") ? 0 : 1;   // one output channel: kh taps in the MFMA rows (conv_q4i_mfma_kernel<..., KHP>)
 
 }  // namespace
 
@@ -561,6 +595,13 @@ static void q4_launch(const QArgs& a, int ntiles, bool aligned, hipStream_t st) 
   if constexpr (NB == 1) {          // (two row blocks: the interleaved variant spills — 72 weight + 64 accumulator + 80 staging registers)
     // channel-interleaved LDS tile, ds_read_b128 operands: 5 % faster on the long channel loops (64 -> 4: 0.835 -> 0.787 ms, 67 -> 4:
     // 0.781 -> 0.753), equal on the short ones
+    if constexpr (!FLIP) {
+      if (a.Cout == 1 && g_q4_khp && (g_q4_ck == 4 || g_q4_ck == 0)) {
+        if (aligned) conv_q4i_mfma_kernel<8, 1, false, true, true><<<ntiles, 256, extra, st>>>(a);
+        else conv_q4i_mfma_kernel<8, 1, false, false, true><<<ntiles, 256, extra, st>>>(a);
+        return;
+      }
+    }
     if (g_q4_ck == 4 || (g_q4_ck == 0 && a.Cin >= 16)) {
       if (aligned) conv_q4i_mfma_kernel<8, NB, FLIP, true><<<ntiles, 256, extra, st>>>(a);
       else conv_q4i_mfma_kernel<8, NB, FLIP, false><<<ntiles, 256, extra, st>>>(a);

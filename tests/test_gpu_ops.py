@@ -852,7 +852,7 @@ def test_stale_descriptor_layouts_are_rejected():
 
 Q4_CASES = [  # (cin, cout, shape): ragged depth / height / width tiles, 1..8 output channels, channel counts off the chunk size
     (64, 4, (8, 16, 128)), (67, 4, (6, 10, 68)), (25, 1, (9, 17, 64)), (4, 8, (5, 8, 100)), (3, 5, (4, 9, 36)), (9, 7, (13, 7, 132)),
-    (1, 2, (3, 3, 4)), (5, 3, (1, 1, 8)), (137, 8, (4, 8, 64)), (2, 6, (7, 25, 60)),
+    (1, 2, (3, 3, 4)), (5, 3, (1, 1, 8)), (137, 8, (4, 8, 64)), (2, 6, (7, 25, 60)), (7, 1, (5, 9, 36)), (30, 1, (12, 16, 128)), (1, 1, (2, 3, 8)),
     # few input channels, many outputs (not this kernel's shapes: the dispatcher must route them elsewhere, also when it is forced)
     (3, 20, (5, 9, 36)), (4, 67, (6, 10, 68)), (1, 9, (4, 4, 8)),
 ]
@@ -909,6 +909,39 @@ def test_conv_q4_kernel_vs_oracle(ops, q4_forced, cin, cout, shape, ck):
     acc3 = base3.clone()
     ops.raw_conv_bwd_data(d3, dy3.to(DEV), w.to(DEV), acc3, accumulate=True)
     assert rel(acc3, base3 + dx3) < 1e-6
+
+
+@pytest.mark.parametrize("cin,shape", [(25, (9, 17, 64)), (7, (5, 9, 36)), (30, (12, 16, 128)), (25, (6, 20, 200))])
+def test_conv_q4_single_output_channel_kh_packed(ops, q4_forced, cin, shape):
+    """The 25 -> 1 output layer's forward kernel (conv_q4i_mfma_kernel<..., KHP>: the three kh taps in the MFMA rows, accumulators per
+    INPUT row, shifted sum in the epilogue): chain on load, bias, statistics, aligned and unaligned rows, ragged tile edges."""
+    import ctypes as C
+    L = q4_forced
+    L.dpi_set_q4(2, 4)
+    gen = torch.Generator().manual_seed(5 + cin)
+    x = torch.randn((1, cin) + shape, generator=gen)
+    chain = torch.stack([torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen), torch.full((cin,), 0.2),
+                         torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen)], dim=1).contiguous()
+    w = torch.randn((1, cin, 3, 3, 3), generator=gen) * 0.1
+    b = torch.randn(1, generator=gen)
+    bc = lambda v: v.reshape(1, -1, 1, 1, 1)
+    tx = bc(chain[:, 3]) * O.activation("LeakyReLU", bc(chain[:, 0]) * x + bc(chain[:, 1])) + bc(chain[:, 4])
+    wg, bg, cg = w.to(DEV), b.to(DEV), chain.to(DEV)
+    for use_chain in (False, True):
+        yr = O.conv_nd((tx if use_chain else x).double(), w.double(), b.double(), 1)
+        for misalign in (0, 1):
+            buf = torch.zeros(x.numel() + 4, device=DEV)
+            xg = buf[misalign:misalign + x.numel()].view(x.shape)
+            xg.copy_(x.to(DEV))
+            d = ops.make_desc(xg, wg, 1)
+            nblk = L.dpi_conv_fwd_stat_blocks(C.byref(d))
+            part = torch.zeros(nblk * 2, dtype=torch.float64, device=DEV)
+            y = torch.full(yr.shape, float("nan"), device=DEV)
+            ops.raw_conv_fwd(d, xg, cg if use_chain else None, wg, bg, y, part)
+            assert rel(y, yr) < 2e-6
+            p = part.view(nblk, 1, 2).sum(0).cpu()
+            np.testing.assert_allclose(p[:, 0].numpy(), yr.sum((0, 2, 3, 4)).numpy(), rtol=1e-5, atol=2e-2)
+            np.testing.assert_allclose(p[:, 1].numpy(), (yr ** 2).sum((0, 2, 3, 4)).numpy(), rtol=1e-5)
 
 
 @pytest.mark.parametrize("cin,cout,shape", [(20, 4, (9, 10, 68)), (9, 3, (8, 8, 64)), (6, 8, (5, 9, 40)), (64, 4, (4, 8, 128)), (4, 19, (5, 9, 72))])
