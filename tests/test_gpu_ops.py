@@ -790,10 +790,10 @@ def _integration_block():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "INTEGRATION.md")) as fp:
         text = fp.read()
-    sec = text[text.index("## 2. Calling the C ABI directly"):]
-    m = re.search(r"```python\n(.*?)```", sec, re.S)
-    assert m and "class ConvDesc" in m.group(1)
-    return root, m.group(1)
+    sec = text[text.index("## 2. Calling the C ABI directly"):text.index("## 2b.")]
+    blocks = re.findall(r"```python\n(.*?)```", sec, re.S)
+    assert len(blocks) == 2 and "class ConvDesc" in blocks[0] and "dpi_conv_bwd_data_dual" in blocks[1]
+    return root, "\n".join(blocks)             # the ABI-300 binding, then the ABI-301 additions (they use `lib` and `ConvDesc` of the first)
 
 
 def test_integration_md_binding_runs_verbatim(ops, monkeypatch):
@@ -813,6 +813,27 @@ def test_integration_md_binding_runs_verbatim(ops, monkeypatch):
         assert y.shape == ref.shape and torch.equal(y, ref)
         yo = O.conv_nd(x.cpu().double(), w.cpu().double(), b.cpu().double(), stride)
         assert rel(y, yo) < 5e-6
+    # the ABI-301 entry points through the argtypes the document declares
+    import ctypes as C
+    lib, ConvDesc = ns["lib"], ns["ConvDesc"]
+    cin, c3, c1, shape = 21, 8, 6, (6, 10, 20)
+    w3 = (0.2 * torch.randn((c3, cin, 3, 3, 3), generator=g)).to(DEV)
+    w1 = (0.2 * torch.randn((c1, cin, 1, 1, 1), generator=g)).to(DEV)
+    dy3, dy1 = torch.randn((1, c3) + shape, generator=g).to(DEV), torch.randn((1, c1) + shape, generator=g).to(DEV)
+    d3 = ConvDesc(C.sizeof(ConvDesc), cin, c3, *shape, 3, 3, 1, 0)
+    d1 = ConvDesc(C.sizeof(ConvDesc), cin, c1, *shape, 1, 1, 1, 0)
+    dx = torch.empty((1, cin) + shape, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.dpi_conv_bwd_data_dual(C.byref(d3), dy3.data_ptr(), w3.data_ptr(), C.byref(d1), dy1.data_ptr(), w1.data_ptr(), dx.data_ptr(), 0, None, 0, st) == 0
+    xr = torch.zeros((1, cin) + shape, dtype=torch.float64, requires_grad=True)
+    ((O.conv_nd(xr, w3.cpu().double(), None, 1) * dy3.cpu().double()).sum() + (O.conv_nd(xr, w1.cpu().double(), None, 1) * dy1.cpu().double()).sum()).backward()
+    assert rel(dx, xr.grad) < 2e-6
+    n = lib.dpi_conv_fwd_ws_floats(C.byref(d3))
+    ws = torch.empty(max(int(n), 1), device=DEV)
+    x = torch.randn((1, cin) + shape, generator=g).to(DEV)
+    y = torch.empty((1, c3) + shape, device=DEV)
+    assert lib.dpi_conv_fwd_ws(C.byref(d3), x.data_ptr(), None, w3.data_ptr(), None, y.data_ptr(), None, ws.data_ptr() if n else None, n, st) == 0
+    assert rel(y, O.conv_nd(x.cpu().double(), w3.cpu().double(), None, 1)) < 2e-6
 
 
 def test_stale_descriptor_layouts_are_rejected():
