@@ -489,16 +489,21 @@ struct BwMArgs {
 
 // TC != 0: the launch covers a final group that holds only TC real channels (Cin = 4m + 1: TC = 1) and computes just their
 // (channel, tap) column tiles: 2 instead of 7 — the padded channels' 80 columns are not multiplied at all.
-template <int KD, int S, int NR, int NH>
+template <int KD, int S, int NR, int NH, int NG = 1>
 struct BwLds {
   using G = Geo<KD, NR, NH, S>;
   static constexpr int NTQ0 = (4 * KD * 9 + 15) / 16;
-  static constexpr int LDSF = 4 * G::CS > 4 * NTQ0 * 256 ? 4 * G::CS : 4 * NTQ0 * 256;   // halo tile of 4 channels / the cross-wave reduction
+  static constexpr int LDSF = NG * (4 * G::CS > 4 * NTQ0 * 256 ? 4 * G::CS : 4 * NTQ0 * 256);   // halo tile of 4 NG channels / the cross-wave reduction
   static constexpr int DYRS = 4 * (4 * NH) + 4;            // row stride of the dY transpose buffer: = 4 (mod 32) -> 2-pass reads
 };
 
-template <int KD, int S, int NR, int NH, int TC>
-__device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a, float* __restrict__ lds, float* __restrict__ dyl_all) {
+// NG = 2: the workgroup stages TWO 4-channel groups per tile and multiplies each dY operand into 14 column tiles instead of 7 — the
+// dY rows (fetch, transpose through LDS, 64 reads per wave and tile), the tile addressing and the two barriers are paid once per 896
+// MFMAs instead of once per 448, and a layer's dY is streamed half as often (70 KB of LDS: two workgroups per CU, which costs this
+// kernel nothing).  first_group: the first of the NG groups this workgroup owns (-1: blockIdx.y, or the XCD-aware 1-D order).
+template <int KD, int S, int NR, int NH, int TC, int NG = 1>
+__device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a, float* __restrict__ lds, float* __restrict__ dyl_all, int first_group = -1) {
+  static_assert(NG == 1 || TC == 0, "the column-trimmed tail is a single group");
 #ifdef DPI_TRACE
   const int trc = (blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 4) ? (int)blockIdx.x : -1;
   int trn = 0;
@@ -520,8 +525,8 @@ __device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a, floa
   const int lk = lane >> 4, lj = lane & 15;
   const int wch = lane >> 2, wp = lane & 3;   // dY fetch mapping: channel, float4 piece
   float* __restrict__ dyw = dyl_all + wid * 16 * DYRS;
-  int chunk = blockIdx.x, group = blockIdx.y;
-  if (a.ngroups > 0) {
+  int chunk = blockIdx.x, group = first_group >= 0 ? first_group : (int)blockIdx.y;
+  if (first_group < 0 && a.ngroups > 0) {
     const int L = blockIdx.x, r = L >> 3;
     group = r % a.ngroups;
     chunk = (r / a.ngroups) * 8 + (L & 7);
@@ -546,14 +551,15 @@ __device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a, floa
   const int lbase = wz * G::SD * G::DS + wh * S * G::RS + lk * S;
   const __amdgpu_buffer_rsrc_t dyb = dpi_buffer(a.dy + (size_t)n0 * Vo, (size_t)min(16, a.Cout - n0) * Vo * sizeof(float));
 
-  f32x4 acc[NTQ];
+  constexpr int NA = NG * NTQ;                 // accumulators / B operands per k-step
+  f32x4 acc[NA];
 #pragma unroll
-  for (int t = 0; t < NTQ; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int t_begin = chunk * a.tiles_per_chunk;
   const int t_end = min(t_begin + a.tiles_per_chunk, a.ntiles);
   int goff[G::E], loff[G::E];
-  float sr[4][G::E];
+  float sr[4][G::E], sr2[NG == 2 ? 4 : 1][NG == 2 ? G::E : 1];
   auto tile_origin = [&](int tile, int& od0, int& oh0, int& ow0) {
     int bt = tile;
     const int tw_i = bt % a.ntw; bt /= a.ntw;
@@ -565,12 +571,14 @@ __device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a, floa
     tile_origin(t_begin, od0, oh0, ow0);
     tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
     stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
+    if constexpr (NG == 2) stage_load<G>(sr2, a.x, a.Cin, V, c0 + 4, goff);
   }
   for (int tile = t_begin; tile < t_end; ++tile) {
     TRW();
     __syncthreads();
     TRW();
     stage_store<G>(lds, sr, a.chain, a.Cin, c0, goff, loff);
+    if constexpr (NG == 2) stage_store<G>(lds + 4 * G::CS, sr2, a.chain, a.Cin, c0 + 4, goff, loff);
     __syncthreads();
     TRW();
     const int cod = od0 + wz, coh0 = oh0 + wh, cow0 = ow0;
@@ -612,37 +620,43 @@ __device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a, floa
       tile_origin(tile + 1, od0, oh0, ow0);
       tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
       stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
+      if constexpr (NG == 2) stage_load<G>(sr2, a.x, a.Cin, V, c0 + 4, goff);
     }
     TRW();
     // Software pipeline (as in the forward kernel): the B operands of step (hr, s + 1) and the A row of hr + 1 are requested
     // BEFORE the 7 MFMAs of step (hr, s) and pinned there with sched_barrier — hipcc otherwise sinks every ds_read to just
     // before its first use and the wave waits out the LDS latency once per step (MFMA pipe 58 % busy, round-2 SQ counters).
-    auto load_b = [&](float (&b)[NTQ], int hr, int s_) {
+    // steps are (row hr, group g, k-step s): the A operands of a row serve both groups, the B operands are 7 per step either way
+    auto load_b = [&](float (&b)[NTQ], int hr, int g, int s_) {
 #pragma unroll
-      for (int t = 0; t < NTQ; ++t) b[t] = lds[lbase + hr * S * G::RS + 4 * s_ * S + toff[t]];
+      for (int t = 0; t < NTQ; ++t) b[t] = lds[g * 4 * G::CS + lbase + hr * S * G::RS + 4 * s_ * S + toff[t]];
     };
     float gc[KS], gn[KS], bc[NTQ], bn[NTQ];
     put_row(raw[0]);
     get_row(gc);
     if (1 < NR) put_row(raw[1]);                             // LDS ops of a wave execute in order: safe after the reads above
-    load_b(bc, 0, 0);
+    load_b(bc, 0, 0, 0);
 #pragma unroll
     for (int hr = 0; hr < NR; ++hr) {
       if (hr + 3 < NR && hr + 3 >= NPRE) load_raw(raw[hr + 3], hr + 3);   // enters the row buffer 1.5 rows from now
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        if (s == KS / 2 && hr + 1 < NR) {                    // next row's A operands; then its successor may enter the row buffer
-          get_row(gn);
-          if (hr + 2 < NR) put_row(raw[hr + 2]);
+      for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          if (g == NG - 1 && s == KS / 2 && hr + 1 < NR) {     // next row's A operands; then its successor may enter the row buffer
+            get_row(gn);
+            if (hr + 2 < NR) put_row(raw[hr + 2]);
+          }
+          if (s + 1 < KS) load_b(bn, hr, g, s + 1);
+          else if (g + 1 < NG) load_b(bn, hr, g + 1, 0);
+          else if (hr + 1 < NR) load_b(bn, hr + 1, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < NTQ; ++t) acc[g * NTQ + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(gc[s], bc[t], acc[g * NTQ + t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < NTQ; ++t) bc[t] = bn[t];
         }
-        if (s + 1 < KS) load_b(bn, hr, s + 1);
-        else if (hr + 1 < NR) load_b(bn, hr + 1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < NTQ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(gc[s], bc[t], acc[t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < NTQ; ++t) bc[t] = bn[t];
       }
       if (hr + 1 < NR) {
 #pragma unroll
@@ -652,16 +666,16 @@ __device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a, floa
   }
   // ---- cross-wave reduction through LDS, then one partial per (chunk, co, ci, tap) ------------------------------------
   __syncthreads();
-  float* red = lds;   // [4 waves][NTQ][4 r][64 lanes]
+  float* red = lds;   // [4 waves][NA][4 r][64 lanes]
 #pragma unroll
-  for (int t = 0; t < NTQ; ++t)
+  for (int t = 0; t < NA; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[((wid * NTQ + t) * 4 + r) * 64 + lane] = acc[t][r];
+    for (int r = 0; r < 4; ++r) red[((wid * NA + t) * 4 + r) * 64 + lane] = acc[t][r];
   __syncthreads();
-  for (int e = tid; e < NTQ * 256; e += 256) {
-    const int l = e & 63, r = (e >> 6) & 3, t = e >> 8;
-    const float sum = red[e] + red[e + NTQ * 256] + red[e + 2 * NTQ * 256] + red[e + 3 * NTQ * 256];
-    const int co = n0 + 4 * (l >> 4) + r, q = t * 16 + (l & 15), ci = c0 + q / TAPS, tap = q % TAPS;
+  for (int e = tid; e < NA * 256; e += 256) {
+    const int l = e & 63, r = (e >> 6) & 3, t = (e >> 8) % NTQ, g = (e >> 8) / NTQ;
+    const float sum = red[e] + red[e + NA * 256] + red[e + 2 * NA * 256] + red[e + 3 * NA * 256];
+    const int co = n0 + 4 * (l >> 4) + r, q = t * 16 + (l & 15), ci = c0 + 4 * g + q / TAPS, tap = q % TAPS;
     if (co < a.Cout && q < NQ && ci < a.Cin) {
       if (a.swap) a.ws[(((size_t)chunk * a.Cin + ci) * a.Cout + co) * TAPS + (TAPS - 1 - tap)] = sum;   // (staged, A) = (co, ci)
       else a.ws[(((size_t)chunk * a.Cout + co) * a.Cin + ci) * TAPS + tap] = sum;
@@ -687,6 +701,19 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_merged_kernel(BwMArg
   __shared__ __attribute__((aligned(16))) float dyl[4 * 16 * L::DYRS];
   if (blockIdx.y + 1 == gridDim.y) conv_bwd_weight_mfma_body<KD, S, NR, NH, 1>(a, lds, dyl);
   else conv_bwd_weight_mfma_body<KD, S, NR, NH, 0>(a, lds, dyl);
+}
+
+// Two groups per workgroup (see NG above): blockIdx.y < npairs owns groups 2y, 2y + 1; then, if the number of full groups is odd, one
+// workgroup column with the last full group alone; then the column-trimmed one-channel tail group if the staged count is 4m + 1.
+template <int KD, int S, int NR, int NH>
+__global__ __launch_bounds__(256, 2) void conv_bwd_weight_mfma_pair_kernel(BwMArgs a, int npairs, int nfull) {
+  using L = BwLds<KD, S, NR, NH, 2>;
+  __shared__ __attribute__((aligned(16))) float lds[L::LDSF];
+  __shared__ __attribute__((aligned(16))) float dyl[4 * 16 * L::DYRS];
+  const int y = blockIdx.y;
+  if (y < npairs) conv_bwd_weight_mfma_body<KD, S, NR, NH, 0, 2>(a, lds, dyl, 2 * y);
+  else if (2 * npairs < nfull && y == npairs) conv_bwd_weight_mfma_body<KD, S, NR, NH, 0, 1>(a, lds, dyl, 2 * npairs);
+  else conv_bwd_weight_mfma_body<KD, S, NR, NH, 1, 1>(a, lds, dyl, nfull);
 }
 
 // ---------------------------------------------------------------- backward-weight, few output channels ---------------
@@ -1169,15 +1196,24 @@ extern "C" void dpi_set_bw_tuning(int want_workgroups, int xcd_order) {
 }
 // occupancy experiments: DPI_BW_EXTRA_LDS=<KiB> of unused dynamic LDS per workgroup (44 KB static: 3 workgroups per CU by default)
 static size_t bw_extra_lds() { static const size_t v = getenv("DPI_BW_EXTRA_LDS") ? (size_t)atoi(getenv("DPI_BW_EXTRA_LDS")) * 1024 : 0; return v; }
-struct MfmaBwPlan { int nchunks, tiles_per_chunk, ntiles, ntd, nth, ntw, nr, nh; };
+struct MfmaBwPlan { int nchunks, tiles_per_chunk, ntiles, ntd, nth, ntw, nr, nh, npairs, nfull, ny; };
+static int g_bw_pair = getenv("DPI_BW_PAIR") ? atoi(getenv("DPI_BW_PAIR")) : 1;   // two 4-channel groups per workgroup (conv_bwd_weight_mfma_pair_kernel)
 static MfmaBwPlan mfma_bw_plan(const dpi_conv_desc* d, bool swap = false) {
   MfmaBwPlan p{};
+  {
+    const int staged = swap ? d->Cout : d->Cin, groups = cdiv(staged, 4);
+    const bool s1k3 = d->stride == 1 && d->kd == 3;
+    const int tailg = (s1k3 && (staged & 3) == 1) ? 1 : 0;
+    p.nfull = groups - tailg;
+    p.npairs = (g_bw_pair && s1k3 && !g_bw_xcd_order && p.nfull >= 2) ? p.nfull / 2 : 0;
+    p.ny = p.npairs ? p.npairs + (p.nfull & 1) + tailg : groups;
+  }
   if (d->stride == 1) { p.nr = 8; p.nh = 2; }
   else { int Do, Ho, Wo; dpi_conv_out_dims(d, &Do, &Ho, &Wo); p.nr = 2; p.nh = Wo > 16 ? 2 : 1; }
   p.ntiles = dpi_mfma_tiles(d, p.nr, p.nh, &p.ntd, &p.nth, &p.ntw);
   const size_t per = (size_t)d->Cout * d->Cin * d->kd * 9;
   const size_t max_chunks_mem = per ? ((size_t)32 << 20) / per : 1;
-  const size_t blocks_other = swap ? (size_t)cdiv(d->Cout, 4) * cdiv(d->Cin, 16) : (size_t)cdiv(d->Cin, 4) * cdiv(d->Cout, 16);
+  const size_t blocks_other = (size_t)p.ny * (swap ? cdiv(d->Cin, 16) : cdiv(d->Cout, 16));
   // ~2304 workgroups (3 per CU x 256 CUs x 3) measured best on the full-resolution layers.  (A model that picks the chunk
   // length by whole occupancy rounds of the main launch was measured 14-17 % SLOWER on every layer, round 2: the kernel is
   // not round-quantised — its limiter is the dY / X re-read traffic, see the XCD-aware workgroup order in the kernel.)
@@ -1214,7 +1250,10 @@ int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const f
     a.ngroups = (int)g.y;
     return dim3(8u * g.y * (unsigned)cdiv((int)g.x, 8), 1, g.z);
   };
-  if (d->stride == 1 && d->kd == 3 && (a.Cin & 3) == 1) {
+  if (p.npairs > 0) {
+    a.ngroups = 0;
+    conv_bwd_weight_mfma_pair_kernel<3, 1, 8, 2><<<dim3(grid.x, p.ny, grid.z), 256, 0, st>>>(a, p.npairs, p.nfull);
+  } else if (d->stride == 1 && d->kd == 3 && (a.Cin & 3) == 1) {
     // staged channel count 4m + 1: full groups in one launch, the one-channel group in a second, column-trimmed one (a single staged
     // channel — the swapped 25 -> 1 output layer — is that second launch alone: 2 column tiles instead of 7)
     static const bool merged = getenv("DPI_BW_TWO_LAUNCHES") == nullptr;
