@@ -32,7 +32,7 @@ def family(path):
         else:
             m = re.match(r"\s+(\w+)\s+n=(\d+) avg=([\d.e+]+)", line)
             if m and m.group(1) in ("FETCH_SIZE", "WRITE_SIZE") and key and (
-                    re.search(r"conv_bwd_weight_mfma(_merged)?_kernel<3, 1, 8, 2", key) or "smallco" in key):
+                    re.search(r"conv_bwd_weight_mfma(_merged|_pair)?_kernel<3, 1, 8, 2", key) or "smallco" in key):
                 rows.append((key, int(m.group(2)), float(m.group(3))))
     return rows
 
@@ -55,7 +55,7 @@ out = {
                         "measured_over_algorithmic": round((read_b + write_b) / 39.18e9, 3),
                         "top_readers_KB_raw_per_iteration": {k: v for k, v in top}},
     "dominant_family": {"family": "conv_bwd_weight k3 s1",
-                        "kernels": "conv_bwd_weight_mfma_kernel<3, 1, 8, 2, *> / conv_bwd_weight_mfma_merged_kernel<3, 1, 8, 2> (both orientations) and conv_bwd_weight_smallco_kernel",
+                        "kernels": "conv_bwd_weight_mfma_kernel<3, 1, 8, 2, *> / conv_bwd_weight_mfma_pair_kernel<3, 1, 8, 2> / ..._merged_kernel (both orientations) and conv_bwd_weight_smallco_kernel",
                         "launches_counted": n_launch, "launches_per_iteration": n_launch / float(iters),
                         "read_bytes_per_iteration": fam_read / iters, "write_bytes_per_iteration": fam_write / iters,
                         "hbm_bytes_per_launch_mean": (fam_read + fam_write) / max(n_launch, 1),
