@@ -372,8 +372,11 @@ def run_c2(a, rank, world, device):
         traffic = traffic_src = moa = None
         if prof and a.precision == prof.get("precision", "fp32"):
             dk = prof.get("dominant_family", {})
+            fk = prof.get("families", {}).get("%s k%d s%d" % dom_key)
             if dk.get("family") == "%s k%d s%d" % dom_key:
                 traffic = dk.get("hbm_bytes_per_launch_mean")
+            elif fk and fam[dom_key]["launches"]:     # per-kernel totals of the whole-iteration passes / this family's launches per iteration
+                traffic = fk["hbm_bytes_per_iteration"] / fam[dom_key]["launches"]
             traffic_src = prof.get("source")
             wi = prof.get("whole_iteration", {})
             if wi.get("hbm_bytes_per_iteration"):

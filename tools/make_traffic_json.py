@@ -61,4 +61,38 @@ out = {
                         "hbm_bytes_per_launch_mean": (fam_read + fam_write) / max(n_launch, 1),
                         "per_grid_KB_raw": {"FETCH_SIZE": [[k, n, v] for k, n, v in fam_f], "WRITE_SIZE": [[k, n, v] for k, n, v in fam_w]}},
 }
+
+
+def kernel_family(name):
+    """3x3x3 stride-1 family of a kernel name of the whole-iteration breakdown (template arguments as rocprofv3 prints them)."""
+    if re.search(r"conv_bwd_weight_mfma(_merged|_pair)?_kernel<3, 1, 8, 2", name) or "smallco" in name:
+        return "conv_bwd_weight k3 s1"
+    m = re.match(r"conv_mfma_kernel<3, \d+, \d+, (true|false), (\d)", name)          # <KD, NR, NH, FLIP, S, ...>
+    if m and m.group(2) == "1":
+        return "conv_bwd_data k3 s1" if m.group(1) == "true" else "conv_fwd k3 s1"
+    m = re.match(r"conv_q4_mfma_kernel<\d+, \d+, \d+, (true|false)", name)          # <R, NB, CK, FLIP, AL>
+    if m:
+        return "conv_bwd_data k3 s1" if m.group(1) == "true" else "conv_fwd k3 s1"
+    m = re.match(r"conv_q4i_mfma_kernel<\d+, \d+, (true|false)", name)               # <R, NB, FLIP, AL, KHP>
+    if m:
+        return "conv_bwd_data k3 s1" if m.group(1) == "true" else "conv_fwd k3 s1"
+    if name.startswith("splitk_reduce_kernel"):
+        return None                                                                   # serves forward and backward-data launches alike: left out
+    return None
+
+
+# every 3x3x3 stride-1 family from the whole-iteration per-kernel breakdown, so that bench.py finds the traffic of whichever family
+# dominates the run (backward-weight and backward-data are within 1 % of each other)
+fams = {}
+for k in set(f_k) | set(w_k):
+    fam = kernel_family(k)
+    if fam:
+        e = fams.setdefault(fam, {"read_bytes_per_iteration": 0.0, "write_bytes_per_iteration": 0.0, "kernels": []})
+        e["read_bytes_per_iteration"] += f_k.get(k, 0.0) * 1024.0 * 2.0
+        e["write_bytes_per_iteration"] += w_k.get(k, 0.0) * 1024.0
+        e["kernels"].append(k)
+for e in fams.values():
+    e["hbm_bytes_per_iteration"] = e["read_bytes_per_iteration"] + e["write_bytes_per_iteration"]
+    e["kernels"].sort()
+out["families"] = fams
 print(json.dumps(out, indent=1))
