@@ -1197,7 +1197,11 @@ extern "C" void dpi_set_bw_tuning(int want_workgroups, int xcd_order) {
 // occupancy experiments: DPI_BW_EXTRA_LDS=<KiB> of unused dynamic LDS per workgroup (44 KB static: 3 workgroups per CU by default)
 static size_t bw_extra_lds() { static const size_t v = getenv("DPI_BW_EXTRA_LDS") ? (size_t)atoi(getenv("DPI_BW_EXTRA_LDS")) * 1024 : 0; return v; }
 struct MfmaBwPlan { int nchunks, tiles_per_chunk, ntiles, ntd, nth, ntw, nr, nh, npairs, nfull, ny; };
-static int g_bw_pair = getenv("DPI_BW_PAIR") ? atoi(getenv("DPI_BW_PAIR")) : 1;   // two 4-channel groups per workgroup (conv_bwd_weight_mfma_pair_kernel)
+// two 4-channel groups per workgroup (conv_bwd_weight_mfma_pair_kernel): 0 off, 1 every layer with >= 2 full groups, 2 (default) only
+// group loops of >= 4 full groups at >= 1024 tiles (25->16, 17->26, 51->32 of the default net).  Every layer is faster in isolation
+// with it, but inside the iteration the weight gradients share the chip with the backward-data chain on another stream and a 79 KB
+// workgroup leaves that chain less room: six alternating bench runs each gave 32.95 (off) / 33.20 (every layer) / 32.84 ms (restricted).
+static int g_bw_pair = getenv("DPI_BW_PAIR") ? atoi(getenv("DPI_BW_PAIR")) : 2;
 static MfmaBwPlan mfma_bw_plan(const dpi_conv_desc* d, bool swap = false) {
   MfmaBwPlan p{};
   {
@@ -1206,6 +1210,10 @@ static MfmaBwPlan mfma_bw_plan(const dpi_conv_desc* d, bool swap = false) {
     const int tailg = (s1k3 && (staged & 3) == 1) ? 1 : 0;
     p.nfull = groups - tailg;
     p.npairs = (g_bw_pair && s1k3 && !g_bw_xcd_order && p.nfull >= 2) ? p.nfull / 2 : 0;
+    if (g_bw_pair == 2) {                                      // restricted: long group loops at the two finest levels only
+      int a_, b_, c_;
+      if (p.nfull < 4 || dpi_mfma_tiles(d, 8, 2, &a_, &b_, &c_) < 1024) p.npairs = 0;
+    }
     p.ny = p.npairs ? p.npairs + (p.nfull & 1) + tailg : groups;
   }
   if (d->stride == 1) { p.nr = 8; p.nh = 2; }
