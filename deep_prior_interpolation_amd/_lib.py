@@ -57,6 +57,7 @@ SIGNATURES = {
     "dpi_set_splitk": (None, [_I]),
     "dpi_conv_bwd_data_dual": (_I, [_DESC, _P, _P, _DESC, _P, _P, _P, _I, _P, _Z, _P]),
     "dpi_set_dual_bwd_data": (None, [_I]),
+    "dpi_set_bw_pair": (None, [_I]),
     "dpi_conv_bwd_weight_ws_floats": (_Z, [_DESC]),
     "dpi_conv_bwd_weight": (_I, [_DESC, _P, _P, _P, _P, _P, _Z, _P]),
     "dpi_set_mfma_min_cout": (None, [_I]),

@@ -1202,6 +1202,7 @@ struct MfmaBwPlan { int nchunks, tiles_per_chunk, ntiles, ntd, nth, ntw, nr, nh,
 // with it, but inside the iteration the weight gradients share the chip with the backward-data chain on another stream and a 79 KB
 // workgroup leaves that chain less room: six alternating bench runs each gave 32.95 (off) / 33.20 (every layer) / 32.84 ms (restricted).
 static int g_bw_pair = getenv("DPI_BW_PAIR") ? atoi(getenv("DPI_BW_PAIR")) : 2;
+extern "C" void dpi_set_bw_pair(int mode) { if (mode >= 0 && mode <= 2) g_bw_pair = mode; }
 static MfmaBwPlan mfma_bw_plan(const dpi_conv_desc* d, bool swap = false) {
   MfmaBwPlan p{};
   {

@@ -115,6 +115,9 @@ int dpi_conv_bwd_data_dual(const dpi_conv_desc* d3, const float* dy3, const floa
                            float* dx, int accumulate, float* ws, size_t ws_floats, void* stream);
 /* 0: dpi_conv_bwd_data_dual always runs two launches (A/B testing; DPI_NO_DUAL in the environment does the same) */
 void dpi_set_dual_bwd_data(int on);
+/* backward-weight, two 4-channel groups per workgroup: 0 off, 1 every layer with >= 2 full groups, 2 (default) the long group loops of
+ * the finest level only (DPI_BW_PAIR in the environment sets the initial value; tests force 1 to cover the kernel on small shapes) */
+void dpi_set_bw_pair(int mode);
 /* dw[Cout][Cin][kd][k][k] = sum_p dy[co][p] * T(x)[ci][p*stride + tap - pad].
  * workspace: float[dpi_conv_bwd_weight_ws_floats(d)].  */
 size_t dpi_conv_bwd_weight_ws_floats(const dpi_conv_desc* d);

@@ -277,6 +277,42 @@ def test_conv_bwd_data_dual_vs_oracle(ops, cin, c3, c1, shape):
     assert torch.equal(dx2, dx3)
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(25, 16, (12, 9, 40)), (8, 13, (8, 8, 32)), (17, 26, (6, 16, 32)), (12, 20, (5, 11, 33)), (51, 32, (4, 8, 32)),
+                                            (137, 8, (8, 8, 32)), (16, 40, (9, 17, 40)), (21, 16, (7, 10, 48))])
+def test_conv_bwd_weight_pair_kernel_vs_oracle(ops, cin, cout, shape):
+    """conv_bwd_weight_mfma_pair_kernel (two 4-channel groups per workgroup) forced onto every layer with >= 2 full groups: even / odd
+    numbers of full groups, the column-trimmed one-channel tail (4m + 1 staged channels), both orientations (137 -> 8 stages dY), a
+    chain on X, ragged tiles — against the fp64 oracle and against the single-group kernels."""
+    from deep_prior_interpolation_amd import _lib
+    L = _lib.load()
+    gen = torch.Generator().manual_seed(cin * 13 + cout)
+    x = torch.randn((1, cin) + shape, generator=gen)
+    chain = torch.stack([torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen), torch.full((cin,), 0.2),
+                         torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen)], dim=1).contiguous()
+    dy = torch.randn((1, cout) + shape, generator=gen)
+    bc = lambda v: v.reshape(1, -1, 1, 1, 1)
+    tx = bc(chain[:, 3]) * O.activation("LeakyReLU", bc(chain[:, 0]) * x + bc(chain[:, 1])) + bc(chain[:, 4])
+    w = torch.zeros((cout, cin, 3, 3, 3))
+    xg, dyg, cg = x.to(DEV), dy.to(DEV), chain.to(DEV)
+    d = ops.make_desc(xg, w.to(DEV), 1)
+    res = {}
+    for mode in (1, 0):
+        L.dpi_set_bw_pair(mode)
+        try:
+            for use_chain in (False, True):
+                dw = torch.full(w.shape, float("nan"), device=DEV)
+                ops.raw_conv_bwd_weight(d, xg, cg if use_chain else None, dyg, dw)
+                res[(mode, use_chain)] = dw
+        finally:
+            L.dpi_set_bw_pair(2)
+    for use_chain in (False, True):
+        wr = w.double().requires_grad_(True)
+        O.conv_nd((tx if use_chain else x).double(), wr, None, 1).backward(dy.double())
+        assert rel(res[(1, use_chain)], wr.grad) < 5e-6
+        assert rel(res[(0, use_chain)], wr.grad) < 5e-6
+        assert rel(res[(1, use_chain)], res[(0, use_chain)]) < 2e-6
+
+
 @pytest.mark.parametrize("name", ["bn3d", "bn2d"])
 def test_bn_golden(golden, ops, name):
     g = golden("ops")[name]
