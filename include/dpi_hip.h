@@ -43,7 +43,7 @@ extern "C" {
 #define DPI_CHAIN_STRIDE 5
 
 const char* dpi_last_error(void);
-/* ABI version: 300 = round 3 (dpi_conv_desc carries its own size as first field), 301 adds dpi_conv_fwd_ws / dpi_conv_bwd_data_ws.  A binding checks `>=` the version it was
+/* ABI version: 300 = round 3 (dpi_conv_desc carries its own size as first field), 301 adds dpi_conv_fwd_ws / dpi_conv_bwd_data_ws / dpi_conv_bwd_data_dual.  A binding checks `>=` the version it was
  * written against and dpi_conv_desc_size() == its own struct size. */
 int dpi_version(void);
 /* Number of devices / properties as HIP sees them (no torch involved). */
