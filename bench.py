@@ -49,7 +49,8 @@ BMIN_CONST = 0.166e9                                               # ... + 28 B 
 FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak (nominal, 2.4 GHz)
 FP32_SUSTAINED_TFLOPS = 154.0     # tools/ubench/mfma_rate: pure v_mfma_f32_16x16x4_f32 stream, 32.25 clk/MFMA at 2.39 GHz
 HBM_PEAK_GBS = 8000.0
-PROFILE_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")   # rocprofv3 --pmc results (cannot be collected in-process)
+# rocprofv3 --pmc results (cannot be collected in-process); each carries the digest of the kernel sources it was collected on
+PROFILE_JSON = {"fp32": os.path.join(ROOT, "profiles", "r04_traffic.json"), "bf16": os.path.join(ROOT, "profiles", "r04_bf16_traffic.json")}
 
 
 def parse():
@@ -171,11 +172,33 @@ def cpu_baseline(patch_full, patch_cpu, upsample, iters, gpu_rate_same_patch):
                                          "note": "work per iteration is proportional to voxels; informational only"}}
 
 
-def load_profile_json():
-    if os.path.exists(PROFILE_JSON):
-        with open(PROFILE_JSON) as fp:
-            return json.load(fp)
-    return None
+def kernel_source_sha256():
+    """sha256 over the kernel sources the benchmarked libdpi_hip.so is built from (csrc/*.hip, *.h, *.cpp, Makefile, include/dpi_hip.h, in
+    sorted order: file name + contents).  tools/make_traffic_json.py stores the same digest next to the PMC figures, so a counter file
+    collected on another build is recognised as stale instead of being quoted."""
+    import hashlib
+    csrc = os.path.join(ROOT, "deep_prior_interpolation_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile")
+    files.append(os.path.join(ROOT, "include", "dpi_hip.h"))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fp:
+            h.update(fp.read())
+    return h.hexdigest()
+
+
+def load_profile_json(precision="fp32"):
+    """(profile or None, stale flag).  The PMC counters cannot be collected in-process; the tracked file is only quoted when it was
+    collected on THIS build of the kernels (digest of the kernel sources) — otherwise roofline.traffic is null and traffic_stale true."""
+    path = PROFILE_JSON.get(precision)
+    if path and os.path.exists(path):
+        with open(path) as fp:
+            prof = json.load(fp)
+        if prof.get("csrc_sha256") == kernel_source_sha256():
+            return prof, False
+        return None, True
+    return None, False
 
 
 FAMILY_NAMES = {
@@ -341,12 +364,10 @@ def run_c2(a, rank, world, device):
         # the all-reduced accumulator must be the sum of the ranks' accumulators (checked on its grand total before normalisation
         # is not possible any more; the normalised volume times hit count times gain sums to the same number)
         gather_ok = gather_ok and bool(torch.isfinite(tot).item())
-    if rank != 0:
-        return None
-    ms = dt / a.steps * 1e3
+    ms = dt / a.steps * 1e3          # (every rank assembles the record — pure host arithmetic — because the configs[2] block below is a collective job)
     iter_flop = FLOP_PER_VOXEL_ITER * V
     bmin = BMIN_PER_VOXEL_ITER * V + BMIN_CONST
-    prof = load_profile_json() if tuple(a.patch) == (256, 128, 128) else None
+    prof, traffic_stale = load_profile_json(a.precision) if tuple(a.patch) == (256, 128, 128) else (None, False)
     roof = None
     fam_rows = []
     for kk, f in sorted(fam.items(), key=lambda it: -it[1]["ms"]):
@@ -391,8 +412,9 @@ def run_c2(a, rank, world, device):
         roof = {"bound": "mfma", "kernel": FAMILY_NAMES.get(dom_key, str(dom_key)) + " @%dx%dx%d: the kernel family with the largest share of the iteration"
                          % tuple(a.patch),
                 "achieved": round(iso, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(iso / FP32_PEAK_TFLOPS, 4),
+                "frac_in_timed_schedule": round(ach / FP32_PEAK_TFLOPS, 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch, mean over the family's launches (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE)",
-                "traffic_source": traffic_src,
+                "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                 "algorithmic_flop_per_iteration": d_iso["flop"], "algorithmic_bytes": d_iso["bytes"] / d_iso["launches"], "launches_per_iteration": d_iso["launches"],
                 "launch_ms": round(d_iso["ms"] / d_iso["launches"], 4), "family_ms_per_iteration": round(d_iso["ms"], 3),
                 "share_of_iteration": round(d_iso["ms"] / ms, 4),
@@ -436,10 +458,12 @@ def run_c2(a, rank, world, device):
     del T, acc
     torch.cuda.empty_cache()
     c3 = None
-    if world == 1 and a.precision == "fp32" and not a.no_c3_extra and tuple(a.patch) == (256, 128, 128):
-        c3 = configs2_extra(a, device)
+    if a.precision == "fp32" and not a.no_c3_extra and tuple(a.patch) == (256, 128, 128):
+        c3 = configs2_extra(a, rank, world, device)        # every rank: the queue is shared and the job ends in an all-reduce
+    if rank != 0:
+        return None
     cpu = None
-    if not (a.no_cpu_baseline or world > 1):
+    if not a.no_cpu_baseline:       # rank 0 only, after the gather (the other ranks are done; nothing collective follows)
         cpu = cpu_baseline(a.patch, a.cpu_patch, a.upsample, a.cpu_iters, gpu_small_patch_rate(a.cpu_patch, a.upsample, device))
     return {"metric": "Adam iters/sec on 3D MultiRes-UNet (whole job over n_gpus; per_gpu beside it); recon SNR(dB) vs ref under config.snr_vs_reference", "value": round(world * a.steps / dt, 4), "unit": "it/s",
             "per_gpu": round(a.steps / dt, 4),
@@ -461,17 +485,28 @@ def run_c2(a, rank, world, device):
             "roofline": roof, "cpu_baseline": cpu, "other_modes": other, "configs2": c3}
 
 
-def configs2_extra(a, device):
-    """BASELINE configs[2] in the default line's record: a short run of the c3 job (queue of 64^3 patches of a 256^3 volume, 6 at a time
-    as replayed hipGraphs, end to end incl. set-up, overlap-add and normalisation) — `python bench.py --workload c3` is the full line."""
+CONFIGS2_QUEUE = 48      # patches of the fixed configs[2] queue in the default line: the SAME job at every N (strong scaling)
+
+
+def configs2_extra(a, rank, world, device):
+    """BASELINE configs[2] in the default line's record, as a STRONG-scaling figure: a fixed queue of 48 64^3 patches of the 256^3 volume
+    (every 7th of the 343 windows of reference data.py:87-130), pulled by ALL ranks from the shared counter, 6 at a time per GPU as
+    replayed hipGraphs, 100 Adam iterations each, end to end incl. set-up, overlap-add, the all-reduce and normalisation.  The job is the
+    same at N = 1, 2, 4, 8, so value(N) / value(1) is the patch-parallel speed-up north_star states its 6x target on
+    (`python bench.py --workload c3` is the weak-scaling line: 12 patches per rank)."""
     import copy
     b = copy.copy(a)
     b.workload, b.patch, b.steps, b.warmup, b.patches, b.concurrent = "c3", [64, 64, 64], 100, 3, 12, 6
-    r = run_c3(b, 0, 1, device)
-    return {"value": r["value"], "unit": "patch-iterations/s (64^3 patches, one GPU, end to end)", "frac_of_fp32_roofline": r["roofline"]["frac"],
-            "roofline_it_per_s": r["roofline"]["peak"], "loop_only_it_per_s": r["roofline"]["loop_only_it_per_s_rank0"],
-            "patches": b.patches, "iterations_per_patch": b.steps, "concurrent": b.concurrent,
-            "workload": "configs[2]: 256^3 synthetic volume, 50 % missing traces, 64^3 patches stride 32 (343 windows), first 12 of the queue"}
+    b.total_patches = CONFIGS2_QUEUE
+    r = run_c3(b, rank, world, device)
+    if rank != 0:
+        return None
+    return {"value": r["value"], "unit": "patch-iterations/s (64^3 patches, whole job over n_gpus, end to end)", "n_gpus": world, "scaling": "strong",
+            "frac_of_fp32_roofline": r["roofline"]["frac"], "roofline_it_per_s_per_gpu": r["roofline"]["peak"],
+            "loop_only_it_per_s": r["roofline"]["loop_only_it_per_s_rank0"], "patches": CONFIGS2_QUEUE, "patches_rank0": r["config"]["patches_rank0"],
+            "iterations_per_patch": b.steps, "concurrent": b.concurrent, "seconds": r["seconds"],
+            "workload": "configs[2]: 256^3 synthetic volume, 50 %% missing traces, 64^3 patches stride 32 (343 windows), a fixed queue of %d of them "
+                        "shared by all ranks (strong scaling: the same job at every n_gpus)" % CONFIGS2_QUEUE}
 
 
 def run_c3(a, rank, world, device):
@@ -486,7 +521,7 @@ def run_c3(a, rank, world, device):
     pe = patch_extractor_for(vshape, args.patch_shape, args.patch_stride, "3d")
     origins = u.window_origins(vshape, pe.dim, pe.stride)
     n_total = len(origins)
-    n_run = min(n_total, a.patches * world)
+    n_run = min(n_total, getattr(a, "total_patches", None) or a.patches * world)     # total_patches: a fixed queue (strong scaling)
     # the queue's first n_run patches, spread over the volume (every 343 // n_run-th window) so masks / content differ
     pick = [int(i) for i in np.linspace(0, n_total - 1, n_run).round()]
     patches = []
@@ -525,10 +560,10 @@ def run_c3(a, rank, world, device):
     roof_rate = FP32_PEAK_TFLOPS * 1e12 / (FLOP_PER_VOXEL_ITER * V)            # 1470 it/s per GPU at 64^3
     loop_rate = len(mine) * a.steps / max(timings.get("loop_s", dt), 1e-9)
     return {"metric": "Adam iters/sec on 3D MultiRes-UNet per GPU", "value": round(rate, 3), "unit": "it/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "split": "f32 (3 x bf16 split)"}[a.precision], "data": "synthetic",
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "seconds": round(dt, 3), "higher_is_better": True,
+            "scaling": "strong" if getattr(a, "total_patches", None) else "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "split": "f32 (3 x bf16 split)"}[a.precision], "data": "synthetic",
             "config": {"workload": "configs[2]: 256^3 synthetic volume, 50 %% missing traces, %dx%dx%d patches stride %d (%d windows); queue of %d "
-                                   "patches (%d per rank) pulled from the shared counter, %d concurrent hipGraph patches per GPU, %d Adam iterations "
+                                   "patches (%d per rank unless the queue is fixed) pulled from the shared counter, %d concurrent hipGraph patches per GPU, %d Adam iterations "
                                    "each; timed end to end incl. per-patch set-up, dpi_overlap_add, the all-reduce and normalisation; a step = one "
                                    "iteration of every patch in the queue" % (tuple(a.patch) + (a.patch[0] // 2, n_total, n_run, a.patches,
                                                                                  a.concurrent, a.steps)),
@@ -660,44 +695,93 @@ def run_selftest(a, rank, world, device):
             "roofline": None, "cpu_baseline": None}
 
 
+def visible_gpu_count():
+    """GPUs this process could give its ranks, WITHOUT any HIP / torch.cuda call: the launcher parent must never create a HIP context
+    (a process that has initialised the GPU must not start GPU children on this pool, and on ROCm even torch.cuda.device_count() goes
+    through hipGetDeviceCount).  From the *_VISIBLE_DEVICES lists when set (the tightest one), else the KFD topology in sysfs (GPU
+    nodes have simd_count > 0; CPU nodes 0).  None = unknown (no list, no readable topology): the ranks then find out themselves."""
+    import glob
+    import re
+    counts = []
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            counts.append(len([t for t in v.split(",") if t.strip()]))
+    n = None
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(path) as fp:
+                m = re.search(r"^simd_count\s+(\d+)", fp.read(), re.M)
+        except OSError:
+            continue
+        n = (n or 0) + (1 if m and int(m.group(1)) > 0 else 0)
+    if n is not None:
+        counts = [min(c, n) for c in counts] or [n]
+    return min(counts) if counts else None
+
+
 def launch_ranks(a):
     """`python bench.py --gpus N` without a launcher: start N rank processes of this script (one per GPU; RANK / LOCAL_RANK /
-    WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment), forward rank 0's JSON line, exit non-zero when a rank
-    fails.  This process never touches the GPU (a process that has initialised HIP must not fork / exec GPU children on this pool;
-    torch.cuda.device_count() does not initialise it)."""
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment), forward rank 0's JSON line.  ALL ranks are polled: the
+    first one that exits non-zero ends the job at once — the others (blocked in the rendezvous, a barrier or the all-reduce) are
+    killed, the failed rank's stderr tail is forwarded and the exit code is non-zero.  This process never touches the GPU: no
+    torch.cuda / HIP call at all (visible_gpu_count reads the environment and sysfs)."""
     import socket
     import subprocess
+    import tempfile
+    import threading
     if a.workload != "selftest" and os.environ.get("DPI_BENCH_ONE_DEVICE") != "1":
-        have = torch.cuda.device_count()
-        if have < a.gpus:
+        have = visible_gpu_count()
+        if have is not None and have < a.gpus:
             raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (a.gpus, have))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    procs, errs = [], []
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        errs.append(tempfile.TemporaryFile())
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = b""
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[-1]))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)     # drain rank 0 while polling
+    reader.start()
     failed = None
+    deadline = time.time() + a.launch_timeout
     try:
-        out0, _ = procs[0].communicate(timeout=a.launch_timeout)
-        for r, p in enumerate(procs):
-            rc = p.wait(timeout=a.launch_timeout)
-            if rc != 0 and failed is None:
-                failed = (r, rc)
-    except subprocess.TimeoutExpired:
-        failed = (-1, "timeout after %d s" % a.launch_timeout)
+        while failed is None:
+            codes = [p.poll() for p in procs]
+            bad = [(r, rc) for r, rc in enumerate(codes) if rc not in (None, 0)]
+            if bad:
+                failed = bad[0]
+            elif all(rc == 0 for rc in codes):
+                break
+            elif time.time() > deadline:
+                failed = (-1, "timeout after %d s" % a.launch_timeout)
+            else:
+                time.sleep(0.2)
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
+        for p in procs:
+            p.wait()
+    reader.join(timeout=5)
     if failed is not None:
-        sys.stderr.write("bench.py: rank %s failed (%s)\n" % failed)
+        sys.stderr.write("bench.py: rank %s failed (%s); the other ranks were stopped\n" % failed)
+        r = failed[0] if failed[0] >= 0 else 0
+        errs[r].seek(0)
+        tail = errs[r].read().decode(errors="replace")[-4000:]
+        if tail:
+            sys.stderr.write("---- stderr of rank %d (tail) ----\n%s\n" % (r, tail))
         raise SystemExit(1)
-    lines = [l for l in out0.decode().splitlines() if l.startswith("{")]
+    for r, f in enumerate(errs):            # warnings of healthy ranks stay visible
+        f.seek(0)
+        txt = f.read().decode(errors="replace")
+        if txt:
+            sys.stderr.write(txt if r == 0 else "".join("[rank %d] %s\n" % (r, l) for l in txt.splitlines()))
+    lines = [l for l in (out0[0] if out0 else b"").decode().splitlines() if l.startswith("{")]
     if not lines:
         sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
         raise SystemExit(1)
@@ -716,6 +800,10 @@ def main():
     if a.workload == "selftest":
         if world > 1:
             torch.distributed.init_process_group("gloo")
+        if os.environ.get("DPI_BENCH_TEST_FAIL_RANK") == str(rank):     # tests/test_distributed.py: a rank that dies AFTER the rendezvous
+            sys.stderr.write("selftest: rank %d exits on purpose (DPI_BENCH_TEST_FAIL_RANK)\n" % rank)
+            sys.stderr.flush()
+            os._exit(3)
         out = run_selftest(a, rank, world, None)
     else:
         if not torch.cuda.is_available():

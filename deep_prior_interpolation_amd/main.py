@@ -146,6 +146,7 @@ class Interpolator:
 
     def optimization_loop(self, net_input=None):
         self.apply_precision()
+        ops.begin_iteration()
         input_ = self.perturbed_input() if net_input is None else net_input
         if self.iiter < self.args.data_forgetting_factor:       # main.py:153-155
             if input_ is self.input_ or net_input is not None:
@@ -254,6 +255,11 @@ class Interpolator:
         dev = self.device
         if self.optimizer is None:
             self.optimizer = FusedAdam(self.net.parameters(), lr=a.lr)
+            # prepared directly (optimize_concurrently, bench.py): the weight-gradient side streams follow THIS patch's size, not
+            # whatever an earlier optimize() in the process left behind; optimize() / bench.py set it before they
+            # call graph_prepare with an optimiser of their own
+            big = int(np.prod(self.img.shape[:-1])) >= (1 << 20)
+            ops.set_weight_grad_overlap(big, in_graph=big)
         opt = self.optimizer
         self._g_state = torch.zeros(8, dtype=torch.float64, device=dev)
         self._g_state[2] = float("inf")
@@ -264,6 +270,7 @@ class Interpolator:
 
         def one_iteration():
             self.apply_precision()
+            ops.begin_iteration()
             opt.zero_grad()
             out_ = self.net(self.perturbed_input())
             loss, metrics = ops.masked_loss(out_, self.img_, self.mask_, kind)

@@ -145,6 +145,27 @@ def _timed(kind, d, launch):
         launch()
 
 
+_ws_cache = {}
+
+
+def _ws_floats(kind, d):
+    """dpi_conv_*_ws_floats(d), memoised per (kind, descriptor): the call re-runs descriptor validation and launch planning, ~150 host
+    round trips per eager iteration otherwise.  Forward / backward-data only, where a stale answer is harmless: the
+    library ignores a workspace it does not need and runs the unsplit launch when it gets none (include/dpi_hip.h); the split /
+    kernel-selection knobs (dpi_set_splitk, dpi_set_q4, ...) are test / tool hooks — `reset_ws_cache()` after flipping one."""
+    key = (kind, d.Cin, d.Cout, d.D, d.H, d.W, d.k, d.kd, d.stride, d.precision, getattr(d, "io", 0))
+    n = _ws_cache.get(key)
+    if n is None:
+        L = _lib.load()
+        n = {"fwd": L.dpi_conv_fwd_ws_floats, "bwd_data": L.dpi_conv_bwd_data_ws_floats}[kind](C.byref(d))
+        _ws_cache[key] = n
+    return n
+
+
+def reset_ws_cache():
+    _ws_cache.clear()
+
+
 def _conv_ws(n, like):
     """Workspace of the input-channel split (coarse levels; dpi_conv_*_ws_floats is 0 for every other launch)."""
     return torch.empty(n, dtype=torch.float32, device=like.device) if n else None
@@ -152,7 +173,7 @@ def _conv_ws(n, like):
 
 def raw_conv_fwd(d, x, chain, w, bias, y, partials=None):
     L = _lib.load()
-    n = L.dpi_conv_fwd_ws_floats(C.byref(d))
+    n = _ws_floats("fwd", d)
     ws = _conv_ws(n, x)
     _timed("conv_fwd", d, lambda: check(L.dpi_conv_fwd_ws(C.byref(d), ptr(x), ptr(chain), ptr(w), ptr(bias), ptr(y),
                                                           ptr(partials), ptr(ws), n, stream()), "dpi_conv_fwd"))
@@ -160,7 +181,7 @@ def raw_conv_fwd(d, x, chain, w, bias, y, partials=None):
 
 def raw_conv_bwd_data(d, dy, w, dx, accumulate=False):
     L = _lib.load()
-    n = L.dpi_conv_bwd_data_ws_floats(C.byref(d))
+    n = _ws_floats("bwd_data", d)
     ws = _conv_ws(n, dy)
     _timed("conv_bwd_data", d, lambda: check(L.dpi_conv_bwd_data_ws(C.byref(d), ptr(dy), ptr(w), ptr(dx), int(accumulate),
                                                                     ptr(ws), n, stream()), "dpi_conv_bwd_data"))
@@ -171,7 +192,7 @@ def raw_conv_bwd_data_dual(d3, dy3, w3, d1, dy1, w1, dx, accumulate=False):
     (Block3d.conv1 + shortcut, ResPath3d.conv3x3 + conv1x1).  One pass over dx where the MFMA stencil kernel serves the 3x3(x3) layer
     (the 1x1x1 term is a few extra MFMAs on operands read straight from dy1), two launches (write, then add) otherwise."""
     L = _lib.load()
-    n = L.dpi_conv_bwd_data_ws_floats(C.byref(d3))
+    n = _ws_floats("bwd_data", d3)
     ws = _conv_ws(n, dy3)
 
     def launch():
@@ -205,6 +226,12 @@ _side_streams = {}
 N_SIDE_STREAMS = int(os.environ.get("DPI_SIDE_STREAMS", "2"))     # weight gradients round-robin over this many side streams (four alternating bench runs each: 32.43 / 32.12 / 32.33 ms with 1 / 2 / 3)
 _side_rr = [0]
 _side_used = set()
+
+
+def begin_iteration():
+    """Top of every iteration (eager or captured): the weight-gradient launches are dealt to the side streams from stream 0 again, so
+    the kernel-to-stream assignment is the same in every iteration and every run."""
+    _side_rr[0] = 0
 
 
 def _side_stream():
@@ -244,7 +271,7 @@ def join_weight_grads():
 
 def raw_conv_bwd_weight(d, x, chain, dy, dw):
     L = _lib.load()
-    n = L.dpi_conv_bwd_weight_ws_floats(C.byref(d))
+    n = L.dpi_conv_bwd_weight_ws_floats(C.byref(d))     # not memoised: the planner knobs (dpi_set_bw_tuning / _pair) change it and too small a workspace is an error
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
     _timed("conv_bwd_weight", d, lambda: check(L.dpi_conv_bwd_weight(C.byref(d), ptr(x), ptr(chain), ptr(dy), ptr(dw),
                                                                      ptr(ws), n, stream()), "dpi_conv_bwd_weight"))

@@ -6,6 +6,9 @@
                                                                                   (-> tests/golden/plateau_96x64x64.npz)
     cd /tmp && python /root/repo/oracle/make_snr_spread.py --mid 128 64 64 --seeds 0 --epochs 1000 --threads 2   (one process per seed)
     cd /tmp && python /root/repo/oracle/make_snr_spread.py --mid 128 64 64 --merge             (-> tests/golden/snr_mid_128x64x64.npz)
+    cd /tmp && python /root/repo/oracle/make_snr_spread.py --mid 256 128 128 --seeds 0 --epochs 3000 --threads 3
+                          (round 4: the bench geometry; ~45 s per iteration, interrupted when the round ends — parts every 25 iterations)
+    cd /tmp && python /root/repo/oracle/make_snr_spread.py --mid 256 128 128 --merge           (-> tests/golden/snr_bench_head_256x128x128.npz)
 
 Drives the reference `Interpolator` (imported from /root/reference through oracle/ref_shim.py, exactly as
 proof_of_concept_3D.ipynb cell 15 does) on the (48,32,32) hyperbolic stand-in: default MulResUnet3D (5 923 614
@@ -125,11 +128,24 @@ def plateau(shape, seeds, epochs, threads):
         print("seed %d: first iteration with SNR > 1 dB: %d" % (p["seed"], esc))
 
 
+def mid_part_dir(shape):
+    """Per-seed parts of a --mid recording: (128,64,64) keeps the round-3 directory, any other shape gets its own."""
+    if tuple(shape) == (128, 64, 64):
+        return os.path.join(OUT, "_snr_mid_parts")
+    return os.path.join(OUT, "_snr_mid_parts_" + "x".join(str(n) for n in shape))
+
+
+def mid_name(shape):
+    """snr_mid_<shape>.npz; the bench geometry (round 4: the HEAD of a 3000-iteration run, as far as the CPU got) is named for what it is."""
+    tag = "x".join(str(n) for n in shape)
+    return ("snr_bench_head_%s.npz" if tuple(shape) == (256, 128, 128) else "snr_mid_%s.npz") % tag
+
+
 def merge_mid(shape):
     """-> tests/golden/snr_mid_<shape>.npz from the per-seed parts (complete or not: `iterations` says how far each seed got)."""
     import hashlib
     tag = "x".join(str(n) for n in shape)
-    files = sorted(glob.glob(os.path.join(OUT, "_snr_mid_parts", "seed*.npz")))
+    files = sorted(glob.glob(os.path.join(mid_part_dir(shape), "seed*.npz")))
     files = [f for f in files if ".tmp." not in f]
     parts = [dict(np.load(f)) for f in files]
     n = min(len(p["loss"]) for p in parts)
@@ -143,7 +159,7 @@ def merge_mid(shape):
         out[k] = np.array([p[k] for p in parts])
     for k in ("loss", "snr", "pcorr"):
         out[k] = np.stack([p[k][:n] for p in parts]).astype(np.float32)
-    np.savez_compressed(os.path.join(OUT, "snr_mid_%s.npz" % tag), **out)
+    np.savez_compressed(os.path.join(OUT, mid_name(shape)), **out)
     print("merged %d seeds at %s, %d common iterations; SNR(out_best) so far %s" % (len(parts), tag, n, np.round(out["snr_out_best"], 2)))
 
 
@@ -178,7 +194,7 @@ if __name__ == "__main__":
     ref_shim.install()
     if a.mid:
         for s in a.seeds:
-            run_seed(s, a.epochs, a.threads, shape=tuple(a.mid), dense=True, part_dir=os.path.join(OUT, "_snr_mid_parts"))
+            run_seed(s, a.epochs, a.threads, shape=tuple(a.mid), dense=True, part_dir=mid_part_dir(a.mid))
         sys.exit(0)
     if a.plateau:
         plateau(a.plateau, a.seeds or [0], a.epochs, a.threads)

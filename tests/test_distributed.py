@@ -152,3 +152,45 @@ def test_bench_launcher_reports_failure():
     """A rank that dies must make `bench.py --gpus N` exit non-zero instead of printing a line from the survivors."""
     rc, out, err = _bench("--gpus", "2", "--workload", "c2", "--steps", "1", env={"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
     assert rc != 0 and out is None
+
+
+def test_bench_launcher_stops_when_a_late_rank_dies():
+    """rank 1 dies AFTER init_process_group while rank 0 sits in a barrier.  The launcher polls every rank, so it
+    must return promptly (not after the 30-minute launch timeout / the c10d timeout), non-zero, with rank 1's stderr forwarded."""
+    import time
+    t0 = time.time()
+    rc, out, err = _bench("--gpus", "2", "--workload", "selftest", "--steps", "2", env={"DPI_BENCH_TEST_FAIL_RANK": "1"})
+    assert rc != 0 and out is None
+    assert "rank 1 failed" in err and "exits on purpose" in err, err
+    assert time.time() - t0 < 120
+
+
+def test_launcher_parent_never_creates_a_hip_context():
+    """the parent of `bench.py --gpus N` counts devices from the environment / sysfs — never through torch.cuda
+    (hipGetDeviceCount on ROCm).  With torch.cuda.device_count / is_available poisoned in the parent only, the selftest job still
+    spawns and finishes; and with an empty HIP_VISIBLE_DEVICES the GPU workload is refused before any rank starts."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys, runpy, torch\n"
+            "def boom(*a, **k):\n"
+            "    raise RuntimeError('launcher parent touched torch.cuda')\n"
+            "if 'WORLD_SIZE' not in os.environ:\n"
+            "    torch.cuda.device_count = boom; torch.cuda.is_available = boom; torch.cuda.init = boom; torch.cuda.set_device = boom\n"
+            "sys.argv = [%r, '--gpus', '2', '--workload', 'c2', '--steps', '1']\n"
+            "runpy.run_path(sys.argv[0], run_name='__main__')\n" % os.path.join(root, "bench.py"))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "only 0 HIP device(s) visible" in r.stderr and "touched torch.cuda" not in r.stderr, r.stderr
+    import bench
+    e2 = dict(os.environ)
+    try:
+        os.environ["HIP_VISIBLE_DEVICES"] = "0,1,2"
+        os.environ.pop("ROCR_VISIBLE_DEVICES", None)
+        os.environ.pop("CUDA_VISIBLE_DEVICES", None)
+        n = bench.visible_gpu_count()
+        assert n is not None and n <= 3
+    finally:
+        os.environ.clear()
+        os.environ.update(e2)

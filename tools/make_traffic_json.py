@@ -3,11 +3,18 @@
 `roofline.measured_over_algorithmic` (profiles/r03_traffic.json).  Units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB (1024 B);
 on gfx950 FETCH_SIZE counts 64-byte units as 32 (MI355X_MICROARCH.md, HBM / rocprofv3 section; confirmed by the round-1 calibration
 on kernels with known byte counts, profiles/r01_traffic_dominant_conv.json): reads = FETCH_SIZE x 2, writes = WRITE_SIZE x 1."""
+import hashlib
 import json
+import os
 import re
 import sys
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_sha256  # noqa: E402  (digest of the kernel sources: bench.py refuses a counter file of another build)
+
 pre, iters = sys.argv[1], int(sys.argv[2])
+precision = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 
 
 def totals(path):
@@ -49,7 +56,9 @@ out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
               "--no-other-modes --no-c3-extra` (tools/profile_r03.sh pmc_iter), weight-gradient side stream off, %d iterations per pass; "
               "units KB = 1024 B; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950" % iters,
-    "precision": "fp32",
+    "precision": precision,
+    "csrc_sha256": kernel_source_sha256(),
+    "libdpi_hip_so_sha256": hashlib.sha256(open(os.path.join(ROOT, "deep_prior_interpolation_amd", "libdpi_hip.so"), "rb").read()).hexdigest(),
     "whole_iteration": {"FETCH_SIZE_KB_per_iteration": f_it, "WRITE_SIZE_KB_per_iteration": w_it, "read_bytes": read_b, "write_bytes": write_b,
                         "hbm_bytes_per_iteration": read_b + write_b, "algorithmic_bytes_per_iteration": 39.18e9,
                         "measured_over_algorithmic": round((read_b + write_b) / 39.18e9, 3),
