@@ -62,6 +62,8 @@ def parse():
                     help="selftest: the launcher / queue / gather plumbing on CPU tensors over gloo (tests/test_distributed.py), no kernels")
     ap.add_argument("--no-c3-extra", action="store_true", help="c2: skip the short configs[2] run reported under `configs2`")
     ap.add_argument("--aa-weight", type=float, default=0.0, help="c4: weight of the anti-aliasing (directional Laplacian) regulariser")
+    ap.add_argument("--net", default="multiunet", choices=["multiunet", "skip"], help="c4: skip = configs[3] as written (2-D Skip hourglass, --skip 4 x 5)")
+    ap.add_argument("--datadim", default="2d", choices=["2d", "2.5d"], help="c4: 2.5d = four shifted copies of the section as channels (the tests' slabs)")
     ap.add_argument("--patch", type=int, nargs=3, default=None)
     ap.add_argument("--upsample", default="linear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -584,8 +586,14 @@ def run_c4(a, rank, world, device):
     from deep_prior_interpolation_amd.parameter import parse_arguments
     z = np.load(os.path.join(ROOT, "tests", "golden", "host.npz"))
     img, mask = z["lines/original"].astype(np.float64), z["lines/mask"].astype(np.float64)
-    argv = ["--imgdir", "lines", "--datadim", "2d", "--net", "multiunet", "--inputdepth", "64", "--upsample", "linear", "--loss", "mae",
+    argv = ["--imgdir", "lines", "--datadim", a.datadim, "--net", a.net, "--inputdepth", "64", "--upsample", "linear", "--loss", "mae",
             "--gain", "1", "--epochs", str(a.steps + a.warmup + 2), "--gpu", "0", "--precision", a.precision]
+    if a.net == "skip":
+        argv += ["--skip", "4", "4", "4", "4", "4"]              # skip.py:5-20 defaults: one skip width per scale
+    if a.datadim == "2.5d":                                      # the slabs of oracle/make_golden.py gen_lines: the section shifted one trace per slice
+        argv += ["--imgchannel", "4", "--slice", "tx"]
+        img = np.stack([np.roll(img[..., 0], k, axis=1) for k in range(4)], axis=-1)
+        mask = np.stack([np.roll(mask[..., 0], 3 * k, axis=1) for k in range(4)], axis=-1)
     if a.aa_weight > 0:
         argv += ["--aa_weight", str(a.aa_weight)]
     args = parse_arguments(argv)
@@ -633,9 +641,9 @@ def run_c4(a, rank, world, device):
     return {"metric": "Adam iters/sec on 2D MultiRes-UNet per GPU (datasets/lines)", "value": round(world * a.steps / dt, 2), "unit": "it/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if a.precision == "fp32" else a.precision, "data": "datasets/lines section (recorded fixture)",
-            "config": {"workload": "configs[3] data: 2-D MulResUnet defaults (%d params) on datasets/lines 170x100, random66 mask, gain 1, MAE, bilinear, "
+            "config": {"workload": "configs[3] data: %s %s defaults (%d params) on datasets/lines 170x100, random66 mask, gain 1, MAE, bilinear, "
                                    "loop mode %s, aa_weight %g; reference notebook: 21 it/s on a V100 (different hardware, no regulariser)"
-                                   % (T.num_params, mode, a.aa_weight), "last_loss": T.history.loss[-1] if T.history.loss else None},
+                                   % (a.datadim, {"multiunet": "MulResUnet", "skip": "Skip (2-D hourglass)"}[a.net], T.num_params, mode, a.aa_weight), "last_loss": T.history.loss[-1] if T.history.loss else None},
             "roofline": {"bound": "launch", "unit": "it/s", "achieved": round(a.steps / dt, 2), "peak": round(1.0 / max(flop_iter / (FP32_PEAK_TFLOPS * 1e12), bmin / (HBM_PEAK_GBS * 1e9)), 1),
                          "frac": round((a.steps / dt) * max(flop_iter / (FP32_PEAK_TFLOPS * 1e12), bmin / (HBM_PEAK_GBS * 1e9)), 5), "traffic": None,
                          "note": "17 000 pixels: 6.2 GFLOP and 0.28 GB per iteration (roofline 0.04 ms); the iteration is ~400 dependent launches of a "

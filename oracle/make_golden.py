@@ -518,6 +518,42 @@ def gen_lines():
                                                          slab, mslab, 2, "lines 2.5d"))
 
 
+def gen_lines_skip():
+    """BASELINE configs[3] as written: the 2.5-D SKIP net on the datasets/lines slabs.  The reference's get_net sends every 2d / 2.5d
+    `--net` that is not unet / attmultiunet / part to MulResUnet (architectures/__init__.py:41-53) and its parser has no `skip` choice,
+    so the 2-D `Skip` class (architectures/skip.py:5-48) is unreachable upstream.  Here the reference's OWN class runs inside the
+    reference's OWN Interpolator: `architectures.get_net` is wrapped (before main.py binds it, main.py:10) to return
+    Skip(...) with the argument mapping get_net uses for Skip3D (architectures/__init__.py:62-72) when args.net == 'skip'."""
+    import architectures
+    from architectures.skip import Skip
+    orig_get_net = architectures.get_net
+
+    def get_net(args, outchannel=1):
+        if args.datadim in ("2d", "2.5d") and args.net == "skip":
+            return Skip(num_input_channels=args.inputdepth, num_output_channels=outchannel, num_channels_down=args.filters,
+                        num_channels_up=args.filters, num_channels_skip=args.skip, upsample_mode=args.upsample, need_bias=True,
+                        act_fun=args.activation, last_act_fun=args.last_activation, dropout=args.dropout)
+        return orig_get_net(args, outchannel)
+    _pa = ref_shim.parse_args
+
+    def parse_skip(a):
+        ar = _pa(a)
+        ar.net = "skip"
+        return ar
+    orig = np.load(os.path.join(ref_shim.REFERENCE_ROOT, "datasets/lines/original.npy")).astype(np.float64)
+    m66 = np.load(os.path.join(ref_shim.REFERENCE_ROOT, "datasets/lines/random66.npy")).astype(np.float64)
+    slab = np.stack([np.roll(orig[..., 0], k, axis=1) for k in range(4)], axis=-1)
+    mslab = np.stack([np.roll(m66[..., 0], 3 * k, axis=1) for k in range(4)], axis=-1)
+    tiny = ["--filters", "4", "8", "16", "--skip", "2", "2", "2", "--inputdepth", "8", "--upsample", "linear", "--gain", "1"]
+    architectures.get_net, ref_shim.parse_args = get_net, parse_skip
+    try:
+        save("net_lines25d_skip_tiny", run_reference_interpolator(["--imgdir", "/nonexistent", "--datadim", "2.5d", "--imgchannel", "4", "--slice", "tx"] + tiny,
+                                                                  slab, mslab, 3, "lines 2.5d skip"))
+        save("net_lines2d_skip_tiny", run_reference_interpolator(["--imgdir", "/nonexistent", "--datadim", "2d"] + tiny, orig, m66, 3, "lines 2d skip"))
+    finally:
+        architectures.get_net, ref_shim.parse_args = orig_get_net, _pa
+
+
 def gen_checkpoint():
     """A checkpoint PRODUCED BY THE REFERENCE (main.py:238-240 torch.save(state_dict) + utils/generic.py:46 write_args) for the
     transfer-learning flow --netdir (main.py:101-110): tests/golden/ckpt_ref/{args.txt, 0_model.pth} + an input/output pair."""
@@ -629,7 +665,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref_shim.install()
     todo = {"ops": gen_ops, "blocks": gen_blocks, "nets": gen_nets, "structure": gen_structure, "host": gen_host,
-            "unet": gen_unet, "skip2d": gen_skip2d, "acts": gen_acts, "operators": gen_operators, "lines": gen_lines, "checkpoint": gen_checkpoint}
+            "unet": gen_unet, "skip2d": gen_skip2d, "acts": gen_acts, "operators": gen_operators, "lines": gen_lines, "lines_skip": gen_lines_skip, "checkpoint": gen_checkpoint}
     for k, fn in todo.items():
         if a.only is None or k in a.only:
             fn()

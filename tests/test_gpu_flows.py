@@ -256,6 +256,46 @@ def test_antialiasing_addon_on_25d_slabs(golden):
     assert abs(T.history.loss[0] - (T.history.df[0] + 0.25 * T.history.reg[0])) < 1e-6 * abs(T.history.loss[0])
 
 
+def test_configs3_as_written_skip_net_on_25d_slabs_with_antialiasing(golden):
+    """BASELINE configs[3] in the stated combination: `--datadim 2.5d --net skip` (2-D Skip hourglass, reference architectures/skip.py:5-48,
+    reached through get_net — a documented deviation, upstream falls through to MulResUnet) on the datasets/lines slabs WITH the
+    anti-aliasing regulariser in the loop.  The net itself is pinned by the reference-recorded trajectory (test_gpu_nets.py,
+    net_lines25d_skip_tiny); here: the same initial state and first input reproduce the reference's iteration-0 data loss with the add-on
+    switched on, the regulariser value matches the numpy oracle on the HIP output, and a 30-iteration run decreases both terms."""
+    from deep_prior_interpolation_amd import utils as u
+    from deep_prior_interpolation_amd.architectures import Skip
+    from deep_prior_interpolation_amd.main import Interpolator
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    g = golden("net_lines25d_skip_tiny")
+    argv = ["--imgdir", "x", "--datadim", "2.5d", "--imgchannel", "4", "--slice", "tx", "--net", "skip", "--filters", "4", "8", "16", "--skip", "2", "2", "2",
+            "--inputdepth", "8", "--upsample", "linear", "--gain", "1", "--gpu", "0", "--aa_weight", "0.25"]
+
+    def make(epochs):
+        a = parse_arguments(argv + ["--epochs", str(epochs)])
+        u.set_seed(0)
+        T = Interpolator(a, "/tmp")
+        T.load_data({"image": g["image"], "mask": g["mask"], "name": "0"})
+        T.build_model()
+        T.build_input()
+        T.build_regularizer()
+        return T
+    T = make(1)
+    assert isinstance(T.net, Skip) and isinstance(T.history, u.HistoryReg) and tuple(T._aa_op.dips.shape) == (1, 4, 170, 100)
+    sd = T.net.state_dict()
+    assert list(sd.keys()) == list(g["init_state"].keys())
+    T.net.load_state_dict({k: torch.from_numpy(np.asarray(v)).to(sd[k].dtype) for k, v in g["init_state"].items()})
+    T.optimize(net_inputs=[torch.from_numpy(g["net_inputs"][0]).cuda()], verbose=False)
+    assert abs(T.history.df[0] - g["loss"][0]) <= 1e-5 * abs(g["loss"][0])          # the data term is the reference's iteration-0 loss
+    out0 = np.asarray(T.out_best, dtype=np.float64).transpose(2, 0, 1)[None]            # (H,W,C) -> BCHW
+    reg_ref = np.abs(O.hale2d_np(out0, T._aa_op.dips.cpu().numpy().astype(np.float64))).mean()
+    assert abs(T.history.reg[0] - reg_ref) < 1e-4 * reg_ref + 1e-9
+    assert abs(T.history.loss[0] - (T.history.df[0] + 0.25 * T.history.reg[0])) < 1e-6 * abs(T.history.loss[0])
+    T = make(30)
+    T.optimize(verbose=False)
+    h = T.history
+    assert len(h) == 30 and np.isfinite(h.loss).all() and h.loss[-1] < 0.7 * h.loss[0] and h.reg[-1] < h.reg[0]
+
+
 @pytest.mark.parametrize("shape", [(20, 18, 36), (17, 19, 22), (32, 32, 64)])
 def test_precision_modes_through_the_loop_at_awkward_shapes(shape):
     """--precision fp32 / bf16 / split through Interpolator.optimize on shapes that mix the kernel families inside one net: rows

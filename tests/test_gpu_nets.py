@@ -61,7 +61,9 @@ NETS = ["net_mulresunet3d_tiny_trilinear_mae", "net_mulresunet3d_tiny_nearest_ms
         "net_skip3d_tiny", "net_mulresunet2d_tiny", "net_mulresunet25d_tiny",
         "net_mulresunet3d_tiny_elu", "net_mulresunet3d_tiny_tanh_sigmoid",
         # BASELINE configs[3] data: the shipped datasets/lines section as --datadim 2d, and tiled into 2.5-D slabs (4 slices as channels)
-        "net_lines2d_tiny", "net_lines25d_tiny"]
+        "net_lines2d_tiny", "net_lines25d_tiny",
+        # configs[3] as written (the 2.5-D SKIP net): the reference's 2-D Skip class inside the reference's Interpolator (oracle/make_golden.py gen_lines_skip)
+        "net_lines2d_skip_tiny", "net_lines25d_skip_tiny"]
 
 
 def _interpolator(g, epochs):

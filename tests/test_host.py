@@ -276,3 +276,25 @@ def test_skip2d_structure(golden):
         assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == jstr(g["keys"])
     with pytest.raises(NotImplementedError):
         Skip(pad="reflection")
+
+
+def test_get_net_reaches_the_2d_skip_net_for_configs3(golden):
+    """BASELINE configs[3] ("--datadim 2.5d skip-net"): `--net skip` with a 2-D / 2.5-D datadim builds the 2-D `Skip` hourglass (upstream's
+    get_net falls through to MulResUnet there, architectures/__init__.py:41-53; documented deviation).  Keys, order and shapes equal the
+    state the REFERENCE's Skip class had inside the reference's Interpolator (oracle/make_golden.py gen_lines_skip)."""
+    from deep_prior_interpolation_amd.architectures import Skip, get_net
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    for name, dd in (("net_lines25d_skip_tiny", ["--datadim", "2.5d", "--imgchannel", "4", "--slice", "tx"]), ("net_lines2d_skip_tiny", ["--datadim", "2d"])):
+        g = golden(name)
+        a = parse_arguments(["--imgdir", "x", "--net", "skip", "--filters", "4", "8", "16", "--skip", "2", "2", "2", "--inputdepth", "8",
+                             "--upsample", "linear"] + dd)
+        ref = jstr(g["args"])
+        assert ref["net"] == "skip" and ref["datadim"] == a.datadim and ref["upsample"] == a.upsample
+        net = get_net(a, 4 if a.datadim == "2.5d" else 1)
+        assert isinstance(net, Skip)
+        assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(np.asarray(v).shape)) for k, v in g["init_state"].items()]
+        assert sum(p.numel() for p in net.parameters()) == int(g["num_params"])
+    a = parse_arguments(["--imgdir", "x", "--datadim", "2d", "--net", "skip"])          # default --skip has one width less than --filters
+    with pytest.raises(ValueError):
+        get_net(a, 1)
+    assert not isinstance(get_net(parse_arguments(["--imgdir", "x", "--datadim", "2d"]), 1), Skip)          # the default stays MulResUnet
