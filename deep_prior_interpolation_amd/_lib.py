@@ -15,16 +15,20 @@ class DpiError(RuntimeError):
     pass
 
 
-ABI_VERSION = 301      # include/dpi_hip.h: dpi_conv_desc starts with its own size (300); dpi_conv_fwd_ws / dpi_conv_bwd_data_ws (301)
+ABI_VERSION = 400      # include/dpi_hip.h: dpi_conv_desc starts with its own size (300); dpi_conv_fwd_ws / dpi_conv_bwd_data_ws (301); `io` + the *_io entry points (400)
+
+# dpi_conv_desc.io bits / the `io` masks of the *_io entry points (bf16 storage of activations, BASELINE configs[4])
+IO_X_BF16, IO_Y_BF16, IO_DY_BF16, IO_DX_BF16 = 1, 2, 4, 8
+STORE_FWD_BF16, STORE_GRAD_BF16 = 1, 2
 
 
 class ConvDesc(C.Structure):
-    """dpi_conv_desc.  ConvDesc(Cin, Cout, D, H, W, k, kd, stride, precision) fills the leading `size` field itself."""
+    """dpi_conv_desc.  ConvDesc(Cin, Cout, D, H, W, k, kd, stride, precision, io) fills the leading `size` field itself."""
     _fields_ = [("size", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
-                ("k", C.c_int), ("kd", C.c_int), ("stride", C.c_int), ("precision", C.c_int)]
+                ("k", C.c_int), ("kd", C.c_int), ("stride", C.c_int), ("precision", C.c_int), ("io", C.c_int)]
 
-    def __init__(self, Cin=0, Cout=0, D=1, H=1, W=1, k=1, kd=1, stride=1, precision=0):
-        super().__init__(C.sizeof(ConvDesc), int(Cin), int(Cout), int(D), int(H), int(W), int(k), int(kd), int(stride), int(precision))
+    def __init__(self, Cin=0, Cout=0, D=1, H=1, W=1, k=1, kd=1, stride=1, precision=0, io=0):
+        super().__init__(C.sizeof(ConvDesc), int(Cin), int(Cout), int(D), int(H), int(W), int(k), int(kd), int(stride), int(precision), int(io))
 
 
 class AdamTensor(C.Structure):
@@ -37,6 +41,7 @@ _Z = C.c_size_t
 _F = C.c_float
 _U64 = C.c_uint64
 _DESC = C.POINTER(ConvDesc)
+_U = C.c_uint
 
 # name -> (restype, argtypes).  Kept in one table so tests can check every symbol of the header is exported.
 SIGNATURES = {
@@ -109,6 +114,18 @@ SIGNATURES = {
     "dpi_pocs_project": (_I, [_P, _P, _P, _Z, _P, _P]),
     "dpi_overlap_add": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
     "dpi_overlap_normalize": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    # ABI 400: the same calls with the storage types of their activation / gradient tensors (`io` before the stream)
+    "dpi_channel_stats_io": (_I, [_P, _P, _I, _Z, _P, _U, _P]),
+    "dpi_chain_apply_io": (_I, [_P, _P, _I, _Z, _P, _U, _P]),
+    "dpi_chain_add_stats_io": (_I, [_P, _P, _P, _P, _I, _Z, _F, _P, _P, _U, _P]),
+    "dpi_bn_bwd_reduce_io": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _I, _Z, _P, _U, _P]),
+    "dpi_bn_bwd_apply_io": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _P, _I, _I, _Z, _P, _P, _P, _U, _P]),
+    "dpi_bn_bwd_apply_fork_io": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _P, _I, _I, _Z, _P, _P, _P,
+                                      _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _U, _P]),
+    "dpi_bn_bwd_apply_dual_io": (_I, [_P, _I, _I, _Z] + [_P, _P, _P, _P, _P, _F, _P, _P, _P, _P] * 2 + [_I, _I, _P, _P, _P, _F, _P, _U, _P]),
+    "dpi_upsample2x_fwd_io": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _U, _P]),
+    "dpi_upsample2x_bwd_io": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _U, _P]),
+    "dpi_noise_add_io": (_I, [_P, _Z, _F, _U64, _P, _P, _U, _P]),
 }
 
 _lib = None

@@ -56,6 +56,71 @@ __device__ __forceinline__ float dpi_buffer_load(__amdgpu_buffer_rsrc_t r, int b
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_offset, 0, 0));
 }
 
+// ---- activation storage types (ABI 400) -------------------------------------------------------------
+// An activation tensor (or the gradient of one) lives in HBM as fp32 or as bf16 (BASELINE configs[4]: bf16 activations, fp32
+// master weights / BatchNorm statistics / Adam).  Arithmetic is fp32 either way: a bf16 element is widened on load (exact) and a
+// result is rounded to nearest-even on store.  The `bf` flags are wave-uniform kernel arguments (dpi_conv_desc.io, the `io` masks of
+// the *_io entry points); pointers keep their `float*` spelling in the argument structs and are indexed in ELEMENTS through these
+// helpers only.  Statistics that describe a stored tensor (BatchNorm partials in a conv epilogue) are taken of the ROUNDED values.
+typedef float dpi_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 dpi_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dpi_bf16_to_f32(unsigned h) { return __builtin_bit_cast(float, h << 16); }
+__device__ __forceinline__ unsigned dpi_pack_bf16(float lo, float hi) {        // one v_cvt_pk_bf16_f32 (round to nearest even)
+  const dpi_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dpi_bf16x2));
+}
+__device__ __forceinline__ unsigned short dpi_f32_to_bf16(float f) { return (unsigned short)(dpi_pack_bf16(f, 0.f) & 0xffffu); }
+__device__ __forceinline__ float dpi_round_bf16(float f) { return dpi_bf16_to_f32(dpi_pack_bf16(f, 0.f) & 0xffffu); }
+// what a store of `v` into a tensor of that type leaves there
+__device__ __forceinline__ float dpi_stored(float v, bool bf) { return bf ? dpi_round_bf16(v) : v; }
+__device__ __forceinline__ float dpi_ld(const float* base, size_t i, bool bf) {
+  return bf ? dpi_bf16_to_f32(reinterpret_cast<const unsigned short*>(base)[i]) : base[i];
+}
+__device__ __forceinline__ void dpi_st(float* base, size_t i, float v, bool bf) {
+  if (bf) reinterpret_cast<unsigned short*>(base)[i] = dpi_f32_to_bf16(v);
+  else base[i] = v;
+}
+// address of element i (a channel plane, a row) as a `float*` spelled pointer for further dpi_ld / dpi_st / dpi_buffer_t use
+__device__ __forceinline__ const float* dpi_at(const float* base, size_t i, bool bf) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + i * (bf ? 2 : 4));
+}
+__device__ __forceinline__ float* dpi_at(float* base, size_t i, bool bf) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + i * (bf ? 2 : 4));
+}
+// buffer resource over n ELEMENTS of that type, and a load of element `idx` through it (idx < 0: out of range -> 0, as dpi_buffer_load)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dpi_buffer_t(const float* base, size_t n, bool bf) { return dpi_buffer(base, n * (bf ? 2 : 4)); }
+__device__ __forceinline__ float dpi_buffer_load_bf16(__amdgpu_buffer_rsrc_t r, int idx) {
+  return dpi_bf16_to_f32((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, idx * 2, 0, 0));
+}
+// four consecutive elements starting at element i (i % 4 == 0 and an aligned base: 16-byte / 8-byte accesses)
+typedef float dpi_f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned dpi_u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 dpi_ld4(const float* base, size_t i, bool bf, bool nt) {
+  if (bf) {
+    const dpi_u32x2v* p = reinterpret_cast<const dpi_u32x2v*>(reinterpret_cast<const unsigned short*>(base) + i);
+    const dpi_u32x2v u = nt ? __builtin_nontemporal_load(p) : *p;
+    return make_float4(__builtin_bit_cast(float, u[0] << 16), __builtin_bit_cast(float, u[0] & 0xffff0000u),
+                       __builtin_bit_cast(float, u[1] << 16), __builtin_bit_cast(float, u[1] & 0xffff0000u));
+  }
+  const dpi_f32x4v* p = reinterpret_cast<const dpi_f32x4v*>(base + i);
+  const dpi_f32x4v v = nt ? __builtin_nontemporal_load(p) : *p;
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void dpi_st4(float* base, size_t i, float4 v, bool bf, bool nt) {
+  if (bf) {
+    dpi_u32x2v* p = reinterpret_cast<dpi_u32x2v*>(reinterpret_cast<unsigned short*>(base) + i);
+    const dpi_u32x2v u = {dpi_pack_bf16(v.x, v.y), dpi_pack_bf16(v.z, v.w)};
+    if (nt) __builtin_nontemporal_store(u, p); else *p = u;
+    return;
+  }
+  dpi_f32x4v* p = reinterpret_cast<dpi_f32x4v*>(base + i);
+  const dpi_f32x4v w = {v.x, v.y, v.z, v.w};
+  if (nt) __builtin_nontemporal_store(w, p); else *p = w;
+}
+// storage types of one convolution launch: input / output tensor of THAT launch (forward: x / y; backward-data: dy / dx)
+static inline bool dpi_io_in(const dpi_conv_desc* d, bool flip) { return (d->io & (flip ? DPI_IO_DY_BF16 : DPI_IO_X_BF16)) != 0; }
+static inline bool dpi_io_out(const dpi_conv_desc* d, bool flip) { return (d->io & (flip ? DPI_IO_DX_BF16 : DPI_IO_Y_BF16)) != 0; }
+
 // ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -37,6 +37,7 @@ struct BwBArgs {
   int Cin, Cout;
   int D, H, W;
   int nth, ntw, ndc, dlen;     // bands (8 rows x 32 columns), depth chunks per band, slices per chunk
+  int xb, dyb;                 // storage type of x / dy in HBM: 1 = bf16 (8-byte pieces of 4 values), 0 = fp32 (16-byte pieces)
 };
 
 constexpr int TW = 32;
@@ -98,8 +99,8 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void conv_bf16_bwd_weight_ker
   const int q = tid & 7, ch = (tid >> 3) & 15, rh = tid >> 7;
   const int gw = u0 + 4 * q;
   const bool xch = ci0 + ch < a.Cin, ych = co0 + ch < a.Cout;
-  const float* __restrict__ xc = a.x + (size_t)(xch ? ci0 + ch : 0) * V;
-  const float* __restrict__ yc = a.dy + (size_t)(ych ? co0 + ch : 0) * V;
+  const float* __restrict__ xc = dpi_at(a.x, (size_t)(xch ? ci0 + ch : 0) * V, a.xb);
+  const float* __restrict__ yc = dpi_at(a.dy, (size_t)(ych ? co0 + ch : 0) * V, a.dyb);
   const Chain cx = load_chain(a.chain, xch ? ci0 + ch : 0);
   int xoff[EX], yoff[EY];
 #pragma unroll
@@ -121,18 +122,18 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void conv_bf16_bwd_weight_ker
   bool x_live[PF];
   auto load_x = [&](int st, int slice) {
     x_live[st] = slice >= 0 && slice < a.D;
-    const float* __restrict__ p = xc + (size_t)(x_live[st] ? slice : 0) * HW;
+    const float* __restrict__ p = dpi_at(xc, (size_t)(x_live[st] ? slice : 0) * HW, a.xb);
 #pragma unroll
     for (int e = 0; e < EX; ++e)
-      xr[st][e] = (x_live[st] && xoff[e] >= 0) ? *reinterpret_cast<const float4*>(p + xoff[e]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xr[st][e] = (x_live[st] && xoff[e] >= 0) ? dpi_ld4(p, xoff[e], a.xb, false) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto load_dy = [&](int st, int slice) {
     const bool live = slice < d1;
-    const float* __restrict__ p = yc + (size_t)(live ? slice : 0) * HW;
+    const float* __restrict__ p = dpi_at(yc, (size_t)(live ? slice : 0) * HW, a.dyb);
 #pragma unroll
     for (int e = 0; e < EY; ++e) {
-      yr[st][e] = (live && yoff[e] >= 0) ? *reinterpret_cast<const float4*>(p + yoff[e]) : make_float4(0.f, 0.f, 0.f, 0.f);
-      hr[st][e] = (live && hdelta != 0 && yoff[e] >= 0) ? p[yoff[e] + hdelta] : 0.f;
+      yr[st][e] = (live && yoff[e] >= 0) ? dpi_ld4(p, yoff[e], a.dyb, false) : make_float4(0.f, 0.f, 0.f, 0.f);
+      hr[st][e] = (live && hdelta != 0 && yoff[e] >= 0) ? dpi_ld(p, yoff[e] + hdelta, a.dyb) : 0.f;
     }
   };
   auto advance = [&]() {
@@ -320,7 +321,7 @@ size_t dpi_conv_bf16_bww_ws_floats(const dpi_conv_desc* d) { return (size_t)bf16
 
 int dpi_conv_bf16_bww_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws, hipStream_t st) {
   const BwBPlan p = bf16_bww_plan(d);
-  BwBArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.nth, p.ntw, p.ndc, p.dlen};
+  BwBArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.nth, p.ntw, p.ndc, p.dlen, (d->io & DPI_IO_X_BF16) != 0, (d->io & DPI_IO_DY_BF16) != 0};
   dim3 grid(p.nchunks, cdiv(d->Cin, 16), cdiv(d->Cout, 16));
   if (d->precision == 2) conv_bf16_bwd_weight_kernel<3, 4><<<grid, 256, 0, st>>>(a);
   else conv_bf16_bwd_weight_kernel<1, 8><<<grid, 256, 0, st>>>(a);

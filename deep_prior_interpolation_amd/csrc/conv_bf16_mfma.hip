@@ -42,6 +42,7 @@ struct BArgs {
   long w_out_stride, w_in_stride;
   int accumulate;
   int debug;     // tuning experiments only (dpi_set_bf16_debug): 1 skip the MFMA phase, 2 skip the global loads, 4 skip the LDS stores
+  int xb, yb;    // storage type of x / y in HBM: 1 = bf16 (dpi_conv_desc.io), 0 = fp32
 };
 
 template <int KD, int NR, int NH>
@@ -147,9 +148,14 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int ci = min(c0 + c, a.Cin - 1);                   // channels past Cin: their weights are zero
-      const __amdgpu_buffer_rsrc_t r = dpi_buffer(a.x + (size_t)ci * V, V * sizeof(float));
+      const __amdgpu_buffer_rsrc_t r = dpi_buffer_t(dpi_at(a.x, (size_t)ci * V, a.xb), V, a.xb);
+      if (a.xb) {                                              // bf16 tensor: half the bytes per staged element, widened exactly
 #pragma unroll
-      for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_buffer_load(r, goff[e] * 4);
+        for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_buffer_load_bf16(r, goff[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_buffer_load(r, goff[e] * 4);
+      }
     }
   };
   auto load_w = [&](int c0) {
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
-        if (co < a.Cout && od < Do && oh < Ho && ow < Wo) acc[t][r] = a.y[(size_t)co * Vo + ((size_t)od * Ho + oh) * Wo + ow];
+        if (co < a.Cout && od < Do && oh < Ho && ow < Wo) acc[t][r] = dpi_ld(a.y, (size_t)co * Vo + ((size_t)od * Ho + oh) * Wo + ow, a.yb);
       }
     }
   }
@@ -265,13 +271,13 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
     const int co = n0 + 4 * lk + r;
     const bool cok = co < a.Cout;
     const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
-    float* __restrict__ yc = a.y + (size_t)(cok ? co : 0) * Vo + vbase;
+    float* __restrict__ yc = dpi_at(a.y, (size_t)(cok ? co : 0) * Vo + vbase, a.yb);
     double s = 0.0, q = 0.0;
     if (interior) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const float v = acc[t][r] + bv;
-        yc[(t / NH) * Wo + (t % NH) * 16] = v;
+        const float v = dpi_stored(acc[t][r] + bv, a.yb);      // statistics describe what is stored
+        dpi_st(yc, (t / NH) * Wo + (t % NH) * 16, v, a.yb);
         if (a.partials) { s += v; q += (double)v * v; }
       }
     } else {
@@ -279,8 +285,8 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
       for (int t = 0; t < NT; ++t) {
         const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
         if (cok && od < Do && oh < Ho && ow < Wo) {
-          const float v = acc[t][r] + bv;
-          yc[(t / NH) * Wo + (t % NH) * 16] = v;
+          const float v = dpi_stored(acc[t][r] + bv, a.yb);
+          dpi_st(yc, (t / NH) * Wo + (t % NH) * 16, v, a.yb);
           s += v;
           q += (double)v * v;
         }
@@ -336,6 +342,9 @@ static bool bf16_pays(const dpi_conv_desc* d, bool flip) {
   const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
   int nr, nh;
   bf16_variant(d, cout, &nr, &nh);
+  // bf16 STORAGE (a tensor of this launch is bf16): every big-tile shape — the 4x4x1 kernel that serves the few-channel layers in fp32
+  // does not take bf16 tensors, and half the staged bytes move the break-even of this (load-bound) kernel
+  if (d->precision == 1 && nr == 4 && (dpi_io_in(d, flip) || dpi_io_out(d, flip))) return true;
   // split mode (six MFMAs and three LDS fragments per position): wins 12-48 % over the fp32 kernels when both channel counts are
   // >= 8 (25<->16, 51<->32, 137<->8, 8<->13), loses with <= 4 channels on either side (64->4: 1.28 vs 0.96 ms)
   if (d->precision == 2) return nr == 4 && cin >= 8 && cout >= 8;
@@ -365,7 +374,8 @@ int dpi_conv_bf16_run(const dpi_conv_desc* d, const float* x, const float* chain
   const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
   int nr, nh;
   bf16_variant(d, cout, &nr, &nh);
-  BArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, accumulate, g_bf16_debug};
+  BArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, accumulate, g_bf16_debug,
+          dpi_io_in(d, flip), dpi_io_out(d, flip)};
   const int ntiles = bf16_tiles(d, nr, nh, &a.ntd, &a.nth, &a.ntw);
   dim3 grid(ntiles, cdiv(cout, 16));
   if (d->precision == 2) {

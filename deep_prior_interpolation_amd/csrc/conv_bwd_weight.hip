@@ -51,6 +51,7 @@ struct BwArgs {
   int Cin, Cout;
   int D, H, W, Do, Ho, Wo;
   int ntd, nth, ntw, ntiles, tiles_per_chunk;
+  int xb, dyb;              // storage type of x / dy: 1 = bf16
 };
 
 template <int KD, int S, int CO_B, int OW, int TZ, int TY>
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(BwArgs a) {
         for (int c = 0; c < CI_B; ++c) {
           const int ci = ci0 + c;
           float v = 0.f;
-          if (ok && ci < a.Cin) v = apply_chain(load_chain(a.chain, ci), a.x[(size_t)ci * V + go]);
+          if (ok && ci < a.Cin) v = apply_chain(load_chain(a.chain, ci), dpi_ld(a.x, (size_t)ci * V + go, a.xb));
           lds[c * CH_LDS + lo] = v;
         }
       }
@@ -126,13 +127,13 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(BwArgs a) {
 #pragma unroll
         for (int co = 0; co < CO_B; ++co) {
           const int cog = co_base + co;
-          const float* gp = a.dy + (size_t)min(cog, a.Cout - 1) * Vo + obase;
+          const float* gp = dpi_at(a.dy, (size_t)min(cog, a.Cout - 1) * Vo + obase, a.dyb);
           if (row_ok && cog < a.Cout && wo_vec && ow + 3 < a.Wo) {
-            const float4 f = *reinterpret_cast<const float4*>(gp);
+            const float4 f = dpi_ld4(gp, 0, a.dyb, false);
             g[co][0] = f.x; g[co][1] = f.y; if (OW > 2) { g[co][2] = f.z; g[co][3] = f.w; }
           } else {
 #pragma unroll
-            for (int o = 0; o < OW; ++o) g[co][o] = (row_ok && cog < a.Cout && ow + o < a.Wo) ? gp[o] : 0.f;
+            for (int o = 0; o < OW; ++o) g[co][o] = (row_ok && cog < a.Cout && ow + o < a.Wo) ? dpi_ld(gp, o, a.dyb) : 0.f;
           }
         }
         const int lbase = wid * CH_LDS + ((tz * SD) * IH + ty * S) * IWP + ltx * OW * S;
@@ -174,6 +175,7 @@ struct BwPwArgs {
   int Cin, Cout;
   size_t V;
   size_t vox_per_chunk;     // multiple of 1024
+  int xb, dyb;
 };
 
 template <int CI_B, int CO_B>
@@ -193,14 +195,14 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_pw_kernel(BwPwArgs a) {
 #pragma unroll
     for (int i = 0; i < CI_B; ++i) {
       const int ci = min(ci0 + i, a.Cin - 1);
-      const float* p = a.x + (size_t)ci * a.V + v0;
+      const float* p = dpi_at(a.x, (size_t)ci * a.V + v0, a.xb);
       const Chain t = load_chain(a.chain, ci);
       if (vec) {
-        const float4 f = *reinterpret_cast<const float4*>(p);
+        const float4 f = dpi_ld4(p, 0, a.xb, false);
         xi[i][0] = f.x; xi[i][1] = f.y; xi[i][2] = f.z; xi[i][3] = f.w;
       } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) xi[i][k] = v0 + k < a.V ? p[k] : 0.f;
+        for (int k = 0; k < 4; ++k) xi[i][k] = v0 + k < a.V ? dpi_ld(p, k, a.xb) : 0.f;
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) xi[i][k] = (v0 + k < a.V) ? apply_chain(t, xi[i][k]) : 0.f;
@@ -208,13 +210,13 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_pw_kernel(BwPwArgs a) {
 #pragma unroll
     for (int o = 0; o < CO_B; ++o) {
       const int co = min(co0 + o, a.Cout - 1);
-      const float* p = a.dy + (size_t)co * a.V + v0;
+      const float* p = dpi_at(a.dy, (size_t)co * a.V + v0, a.dyb);
       if (vec) {
-        const float4 f = *reinterpret_cast<const float4*>(p);
+        const float4 f = dpi_ld4(p, 0, a.dyb, false);
         g[o][0] = f.x; g[o][1] = f.y; g[o][2] = f.z; g[o][3] = f.w;
       } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) g[o][k] = v0 + k < a.V ? p[k] : 0.f;
+        for (int k = 0; k < 4; ++k) g[o][k] = v0 + k < a.V ? dpi_ld(p, k, a.dyb) : 0.f;
       }
     }
 #pragma unroll
@@ -312,7 +314,9 @@ extern "C" int dpi_conv_bwd_weight(const dpi_conv_desc* d, const float* x, const
   DPI_REQUIRE((d->k == 1 || d->k == 3) && (d->kd == d->k || d->kd == 1) && (d->stride == 1 || d->stride == 2),
               "conv_bwd_weight: unsupported k=%d kd=%d stride=%d", d->k, d->kd, d->stride);
   hipStream_t st = (hipStream_t)stream;
-  if (dpi_conv_bf16_bww_usable(d) && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0) {     // 16-byte staging loads
+  // staging loads of 4 values: 16 bytes from an fp32 tensor, 8 from a bf16 one
+  const uintptr_t misal = ((uintptr_t)x & ((d->io & DPI_IO_X_BF16) ? 7 : 15)) | ((uintptr_t)dy & ((d->io & DPI_IO_DY_BF16) ? 7 : 15));
+  if (dpi_conv_bf16_bww_usable(d) && misal == 0) {
     if (ws_floats < dpi_conv_bf16_bww_ws_floats(d)) {
       dpi_set_error("conv_bwd_weight: workspace %zu < %zu floats", ws_floats, dpi_conv_bf16_bww_ws_floats(d));
       return DPI_E_WORKSPACE;
@@ -349,12 +353,12 @@ extern "C" int dpi_conv_bwd_weight(const dpi_conv_desc* d, const float* x, const
   int Do, Ho, Wo;
   dpi_conv_out_dims(d, &Do, &Ho, &Wo);
   if (d->k == 1) {
-    BwPwArgs a{x, x_chain, dy, ws, d->Cin, d->Cout, (size_t)Do * Ho * Wo, p.vox_per_chunk};
+    BwPwArgs a{x, x_chain, dy, ws, d->Cin, d->Cout, (size_t)Do * Ho * Wo, p.vox_per_chunk, (d->io & DPI_IO_X_BF16) != 0, (d->io & DPI_IO_DY_BF16) != 0};
     dim3 grid(p.nchunks, cdiv(d->Cin, 4), cdiv(d->Cout, 8));
     conv_bwd_weight_pw_kernel<4, 8><<<grid, 256, 0, st>>>(a);
   } else {
     BwArgs a{x, x_chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, Do, Ho, Wo,
-             p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk};
+             p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk, (d->io & DPI_IO_X_BF16) != 0, (d->io & DPI_IO_DY_BF16) != 0};
     dim3 grid(p.nchunks, cdiv(d->Cin, 4), cdiv(d->Cout, 4));
     if (d->kd == 3) {
       if (d->stride == 1) conv_bwd_weight_kernel<3, 1, 4, 4, 4, 8><<<grid, 256, 0, st>>>(a);

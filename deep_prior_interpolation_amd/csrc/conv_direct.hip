@@ -28,6 +28,7 @@ struct ConvArgs {
   int ntd, nth, ntw;  // tiles
   long w_out_stride, w_in_stride;
   int accumulate;
+  int xb, yb;         // storage type of x / y in HBM: 1 = bf16 (dpi_conv_desc.io), 0 = fp32
 };
 
 template <int KD, int S, int CO_B, int OW, int TZ, int TY, int TX, int CI_B, bool FLIP>
@@ -87,13 +88,13 @@ __global__ __launch_bounds__(TZ* TY* TX) void conv_direct_kernel(ConvArgs a) {
     for (int c = 0; c < CI_B; ++c) {
       const int ci = ci0 + c;
       if (ci < a.Cin) {
-        const float* __restrict__ xc = a.x + (size_t)ci * V;
+        const float* __restrict__ xc = dpi_at(a.x, (size_t)ci * V, a.xb);
         const Chain t = load_chain(a.chain, ci);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           if (loff[e] >= 0) {
             float v = 0.f;
-            if (goff[e] >= 0) v = apply_chain(t, xc[goff[e]]);
+            if (goff[e] >= 0) v = apply_chain(t, dpi_ld(xc, goff[e], a.xb));
             lds[c * CH_LDS + loff[e]] = v;
           }
         }
@@ -143,25 +144,28 @@ __global__ __launch_bounds__(TZ* TY* TX) void conv_direct_kernel(ConvArgs a) {
     const bool cok = cog < a.Cout;
     const float b = (a.bias && cok) ? a.bias[cog] : 0.f;
     double s = 0.0, q = 0.0;
-    float* yp = a.y + (size_t)min(cog, a.Cout - 1) * Vo + obase;
+    float* yp = dpi_at(a.y, (size_t)min(cog, a.Cout - 1) * Vo + obase, a.yb);
     float v[OW];
 #pragma unroll
     for (int o = 0; o < OW; ++o) v[o] = acc[co][o] + b;
     if (cok && row_ok) {
       if (vec_ok) {
         if (a.accumulate) {
-          const float4 old = *reinterpret_cast<const float4*>(yp);
+          const float4 old = dpi_ld4(yp, 0, a.yb, false);
           v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
         }
-        *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int o = 0; o < OW; ++o) v[o] = dpi_stored(v[o], a.yb);       // statistics describe what is stored
+        dpi_st4(yp, 0, make_float4(v[0], v[1], v[2], v[3]), a.yb, false);
 #pragma unroll
         for (int o = 0; o < OW; ++o) { s += v[o]; q += (double)v[o] * v[o]; }
       } else {
 #pragma unroll
         for (int o = 0; o < OW; ++o)
           if (ow + o < a.Wo) {
-            if (a.accumulate) v[o] += yp[o];
-            yp[o] = v[o];
+            if (a.accumulate) v[o] += dpi_ld(yp, o, a.yb);
+            v[o] = dpi_stored(v[o], a.yb);
+            dpi_st(yp, o, v[o], a.yb);
             s += v[o]; q += (double)v[o] * v[o];
           }
       }
@@ -203,6 +207,7 @@ struct PwArgs {
   size_t V;
   long w_out_stride, w_in_stride;
   int accumulate;
+  int xb, yb;
 };
 
 template <int CO_B>
@@ -218,15 +223,15 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(PwArgs a) {
     for (int o = 0; o < 4; ++o) acc[c][o] = 0.f;
 #pragma unroll 2
   for (int ci = 0; ci < a.Cin; ++ci) {
-    const float* __restrict__ xc = a.x + (size_t)ci * a.V;
+    const float* __restrict__ xc = dpi_at(a.x, (size_t)ci * a.V, a.xb);
     const Chain t = load_chain(a.chain, ci);
     float in[4];
     if (full) {
-      const float4 f = *reinterpret_cast<const float4*>(xc + v0);
+      const float4 f = dpi_ld4(xc, v0, a.xb, false);
       in[0] = f.x; in[1] = f.y; in[2] = f.z; in[3] = f.w;
     } else {
 #pragma unroll
-      for (int o = 0; o < 4; ++o) in[o] = (v0 + o < a.V) ? xc[v0 + o] : 0.f;
+      for (int o = 0; o < 4; ++o) in[o] = (v0 + o < a.V) ? dpi_ld(xc, v0 + o, a.xb) : 0.f;
     }
 #pragma unroll
     for (int o = 0; o < 4; ++o) in[o] = apply_chain(t, in[o]);
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(PwArgs a) {
     const int cog = co_base + co;
     const bool cok = cog < a.Cout;
     const float b = (a.bias && cok) ? a.bias[cog] : 0.f;
-    float* yp = a.y + (size_t)min(cog, a.Cout - 1) * a.V + v0;
+    float* yp = dpi_at(a.y, (size_t)min(cog, a.Cout - 1) * a.V + v0, a.yb);
     double s = 0.0, q = 0.0;
     float v[4];
 #pragma unroll
@@ -252,18 +257,21 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(PwArgs a) {
     if (cok) {
       if (full) {
         if (a.accumulate) {
-          const float4 old = *reinterpret_cast<const float4*>(yp);
+          const float4 old = dpi_ld4(yp, 0, a.yb, false);
           v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
         }
-        *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) v[o] = dpi_stored(v[o], a.yb);
+        dpi_st4(yp, 0, make_float4(v[0], v[1], v[2], v[3]), a.yb, false);
 #pragma unroll
         for (int o = 0; o < 4; ++o) { s += v[o]; q += (double)v[o] * v[o]; }
       } else {
 #pragma unroll
         for (int o = 0; o < 4; ++o)
           if (v0 + o < a.V) {
-            if (a.accumulate) v[o] += yp[o];
-            yp[o] = v[o];
+            if (a.accumulate) v[o] += dpi_ld(yp, o, a.yb);
+            v[o] = dpi_stored(v[o], a.yb);
+            dpi_st(yp, o, v[o], a.yb);
             s += v[o]; q += (double)v[o] * v[o];
           }
       }
@@ -302,6 +310,7 @@ struct BwdS2Args {
   int D, H, W, Do, Ho, Wo;
   int kd;
   int accumulate;
+  int dyb, dxb;       // storage type of dy / dx: 1 = bf16
 };
 
 template <int CI_B>
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(256) void conv_bwd_data_s2_kernel(BwdS2Args a) {
         const int tap = (kd * 3 + kh) * 3 + kw;
         const size_t o = ((size_t)od * a.Ho + oh) * a.Wo + ow;
         for (int co = 0; co < a.Cout; ++co) {
-          const float g = a.dy[(size_t)co * Vo + o];
+          const float g = dpi_ld(a.dy, (size_t)co * Vo + o, a.dyb);
 #pragma unroll
           for (int c = 0; c < CI_B; ++c) {
             const int ci = min(ci_base + c, a.Cin - 1);
@@ -348,8 +357,8 @@ __global__ __launch_bounds__(256) void conv_bwd_data_s2_kernel(BwdS2Args a) {
   for (int c = 0; c < CI_B; ++c) {
     const int ci = ci_base + c;
     if (ci < a.Cin) {
-      float* p = a.dx + (size_t)ci * V + vox;
-      *p = a.accumulate ? *p + acc[c] : acc[c];
+      const size_t o = (size_t)ci * V + vox;
+      dpi_st(a.dx, o, a.accumulate ? dpi_ld(a.dx, o, a.dxb) + acc[c] : acc[c], a.dxb);
     }
   }
 }
@@ -437,6 +446,8 @@ int dpi_check_conv_desc(const dpi_conv_desc* d) {
   DPI_REQUIRE((size_t)d->D * d->H * d->W < (1ull << 29), "conv: spatial volume %d x %d x %d exceeds the 32-bit byte offsets of the kernels (2^29 voxels per patch)",
               d->D, d->H, d->W);
   DPI_REQUIRE(d->precision >= 0 && d->precision <= 2, "conv: precision must be 0 (fp32), 1 (bf16 operands) or 2 (three-term bf16 split), got %d", d->precision);
+  DPI_REQUIRE((d->io & ~(DPI_IO_X_BF16 | DPI_IO_Y_BF16 | DPI_IO_DY_BF16 | DPI_IO_DX_BF16)) == 0, "conv: unknown storage-type bits in io = %d", d->io);
+  // 8-byte pieces of bf16 rows go through 32-bit ELEMENT offsets of up to 16 channels (backward-weight): the same 2^29-voxel bound covers them
   return DPI_OK;
 }
 
@@ -494,7 +505,7 @@ extern "C" int dpi_conv_fwd_stat_blocks(const dpi_conv_desc* d) {
     if (dpi_mfma_half_tile(d, false)) nr = 4;
     return dpi_mfma_tiles(d, nr, nh, &a, &b, &c);
   }
-  if (g_fewco_mfma && dpi_conv_fewco_usable(d)) { int a, b, c; return dpi_conv_fewco_tiles(d, &a, &b, &c); }
+  if (g_fewco_mfma && !(d->io & (DPI_IO_X_BF16 | DPI_IO_Y_BF16)) && dpi_conv_fewco_usable(d)) { int a, b, c; return dpi_conv_fewco_tiles(d, &a, &b, &c); }
   const Geo g = conv_geo(d->kd, d->stride);
   return cdiv(Do, g.tz) * cdiv(Ho, g.ty) * cdiv(Wo, g.txow);
 }
@@ -517,20 +528,21 @@ static int conv_run(const dpi_conv_desc* d, const float* x, const float* chain, 
   const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
   if (dpi_conv_bf16_usable(d, flip)) return dpi_conv_bf16_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
   if (dpi_conv_q4_usable(d, flip)) return dpi_conv_q4_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
+  const int xb = dpi_io_in(d, flip), yb = dpi_io_out(d, flip);
   if (d->k == 3 && cout >= g_mfma_min_cout && (d->stride == 1 || !flip))
     return dpi_conv_mfma_run(d, x, chain, w, bias, y, partials, flip, accumulate, ws, ws_floats, st);
   if (d->k == 1 && cout >= g_mfma_min_cout) return dpi_conv_pw_mfma_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
-  if (!flip && !accumulate && g_fewco_mfma && dpi_conv_fewco_usable(d)) return dpi_conv_fewco_mfma_run(d, x, chain, w, bias, y, partials, st);
+  if (!flip && !accumulate && g_fewco_mfma && !xb && !yb && dpi_conv_fewco_usable(d)) return dpi_conv_fewco_mfma_run(d, x, chain, w, bias, y, partials, st);
   const int co_b = pick_co_b(cout);
   if (d->k == 1) {
-    PwArgs a{x, chain, w, bias, y, partials, cin, cout, (size_t)Do * Ho * Wo, w_out, w_in, accumulate};
+    PwArgs a{x, chain, w, bias, y, partials, cin, cout, (size_t)Do * Ho * Wo, w_out, w_in, accumulate, xb, yb};
     dim3 grid((unsigned)cdivz(a.V, 1024), cdiv(cout, co_b));
     launch_pw_co(a, co_b, grid, st);
     return dpi_check_launch("conv_pw");
   }
   const Geo g = conv_geo(d->kd, d->stride);
   ConvArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, Do, Ho, Wo,
-             cdiv(Do, g.tz), cdiv(Ho, g.ty), cdiv(Wo, g.txow), w_out, w_in, accumulate};
+             cdiv(Do, g.tz), cdiv(Ho, g.ty), cdiv(Wo, g.txow), w_out, w_in, accumulate, xb, yb};
   dim3 grid(a.ntd * a.nth * a.ntw, cdiv(cout, co_b));
   if (d->kd == 3) {
     if (d->stride == 1) { if (flip) launch_co<3, 1, true>(a, co_b, grid, st); else launch_co<3, 1, false>(a, co_b, grid, st); }
@@ -601,7 +613,7 @@ extern "C" int dpi_conv_bwd_data_ws(const dpi_conv_desc* d, const float* dy, con
   if (d->Cin >= g_mfma_min_cout) return dpi_conv_bwd_data_s2_mfma_run(d, dy, w, dx, accumulate, st);
   int Do, Ho, Wo;
   dpi_conv_out_dims(d, &Do, &Ho, &Wo);
-  BwdS2Args a{dy, w, dx, d->Cin, d->Cout, d->D, d->H, d->W, Do, Ho, Wo, d->kd, accumulate};
+  BwdS2Args a{dy, w, dx, d->Cin, d->Cout, d->D, d->H, d->W, Do, Ho, Wo, d->kd, accumulate, (d->io & DPI_IO_DY_BF16) != 0, (d->io & DPI_IO_DX_BF16) != 0};
   const size_t V = (size_t)d->D * d->H * d->W;
   dim3 grid((unsigned)cdivz(V, 256), cdiv(d->Cin, 8));
   conv_bwd_data_s2_kernel<8><<<grid, 256, 0, st>>>(a);

@@ -46,6 +46,9 @@ struct MArgs {
   const float* __restrict__ w2;
   int C2;
   long w2_co_stride, w2_c_stride;
+  // storage type of the input tensor(s) x / x2 and of the output y in HBM: 1 = bf16, 0 = fp32 (dpi_conv_desc.io; common.h).
+  // A split launch (split_cps > 0) writes fp32 partials into the workspace whatever y is; splitk_reduce_kernel stores y.
+  int xb, yb;
 };
 
 // Tile geometry.  A wave owns NR output rows x NH 16-voxel column blocks; the 4 waves of a workgroup own
@@ -105,7 +108,17 @@ __device__ __forceinline__ void tile_slots(int tid, int id0, int ih0, int iw0, i
 // outside the volume carry goff = -1 -> byte offset -4 -> out of range -> 0 from the hardware (the zero padding).
 template <class G>
 __device__ __forceinline__ void stage_load(float (&sr)[4][G::E], const float* __restrict__ x, int Cin, size_t V, int c0,
-                                           const int (&goff)[G::E]) {
+                                           const int (&goff)[G::E], bool xb = false) {
+  if (xb) {      // bf16 tensor (wave-uniform): 2-byte loads, widened exactly; the same slots, half the bytes
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ci = min(c0 + c, Cin - 1);
+      const __amdgpu_buffer_rsrc_t r = dpi_buffer_t(dpi_at(x, (size_t)ci * V, true), V, true);
+#pragma unroll
+      for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_buffer_load_bf16(r, goff[e]);
+    }
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     // channels past Cin re-read the last real channel: their WEIGHTS are zero (load_w), so no uniform branch is needed
@@ -163,8 +176,12 @@ __device__ long long g_trace[4][64];
 // Instead of 27 MFMAs per output tile with three zero K-slices, that channel's taps are packed four to an MFMA
 // (K = tap 4g + lk; the staged group holds the channel in all four slots, so lane group lk reads its own slot at its own
 // tap offset): 7 MFMAs per tile, -10.6 % of all MFMAs for Cin = 25.
-template <int KD, int NR, int NH, bool FLIP, int S = 1, int WPE = 2, bool PERSIST = false, bool TAILPACK = false>
+// IOB: the launch reads or writes a bf16 tensor (MArgs::xb / yb).  A template parameter, not just a run-time flag: the second load / store
+// path costs the register-capped fp32 variants 12-70 bytes of scratch per lane (measured on the ISA), so the fp32 instantiations are
+// compiled without it.
+template <int KD, int NR, int NH, bool FLIP, int S = 1, int WPE = 2, bool PERSIST = false, bool TAILPACK = false, bool IOB = false>
 __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
+  if constexpr (!IOB) { a.xb = 0; a.yb = 0; }
   using G = Geo<KD, NR, NH, S>;
   constexpr int TAPS = KD * 9;
   constexpr int PD = (KD - 1) / 2;
@@ -222,13 +239,13 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
   };
 
   const int c_lo = a.split_cps ? (int)blockIdx.z * a.split_cps : 0;
-  float* __restrict__ const ybase = a.y + (size_t)blockIdx.z * a.Cout * Vo;
+  float* __restrict__ const ybase = a.y + (size_t)blockIdx.z * a.Cout * Vo;      // (blockIdx.z > 0 only in split launches: fp32 workspace)
   int goff[G::E], loff[G::E];
   float wr[TAPS], wn[9], sr[4][G::E];
   int vt = blockIdx.x, tile_id, od0, oh0, ow0;
   tile_origin(vt, tile_id, od0, oh0, ow0);
   tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
-  stage_load<G>(sr, a.x, a.Cin, V, c_lo, goff);
+  stage_load<G>(sr, a.x, a.Cin, V, c_lo, goff, a.xb);
   {
     bool ok;
     const float* __restrict__ wp = w_ptr(c_lo, ok);
@@ -287,7 +304,7 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
-          if (co < a.Cout && od < Do && oh < Ho && ow < Wo) acc[t][r] = ybase[(size_t)co * Vo + ((size_t)od * Ho + oh) * Wo + ow];
+          if (co < a.Cout && od < Do && oh < Ho && ow < Wo) acc[t][r] = dpi_ld(ybase, (size_t)co * Vo + ((size_t)od * Ho + oh) * Wo + ow, a.yb);
         }
       }
     }
@@ -302,10 +319,10 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
       TRC(4 + (c0 / 4) * 4);
       const bool more = c0 + 4 < cin_main;
       const bool tail_next = tail && !more;
-      if (more || tail_next) stage_load<G>(sr, a.x, a.Cin, V, c0 + 4, goff);   // prefetch the next group behind this one's MFMAs
+      if (more || tail_next) stage_load<G>(sr, a.x, a.Cin, V, c0 + 4, goff, a.xb);   // prefetch the next group behind this one's MFMAs
       else if (has_next) {                                        // ... or the first chunk of the next tile
         tile_slots<G>(tid, od_n * G::SD - PD, oh_n * S - 1, ow_n * S - 1, a.D, a.H, a.W, goff, loff);
-        stage_load<G>(sr, a.x, a.Cin, V, c_lo, goff);
+        stage_load<G>(sr, a.x, a.Cin, V, c_lo, goff, a.xb);
       }
       // software-pipelined walk over (kd, input row): LDS values of step s+1 are requested before the MFMAs of step s
       float bc[G::NB], bn[G::NB];
@@ -356,7 +373,7 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
         __syncthreads();
         if (has_next) {
           tile_slots<G>(tid, od_n * G::SD - PD, oh_n * S - 1, ow_n * S - 1, a.D, a.H, a.W, goff, loff);
-          stage_load<G>(sr, a.x, a.Cin, V, 0, goff);
+          stage_load<G>(sr, a.x, a.Cin, V, 0, goff, a.xb);
         }
 #pragma unroll
         for (int hr = 0; hr < NR; ++hr) {
@@ -377,7 +394,7 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
       // 1x1x1 contribution: D[co][vox] += A[co][c 4] * B[c 4][vox] per 4-channel group of x2, B straight from global memory in MFMA
       // layout (lane = (c = lk, vox = lj): 64 B per channel and row segment; each value is used by this wave only, so LDS would
       // add nothing).  ONE buffer over all of x2: channels >= C2 and out-of-volume voxels are out of range -> 0.
-      const __amdgpu_buffer_rsrc_t r2 = dpi_buffer(a.x2, (size_t)a.C2 * Vo * sizeof(float));
+      const __amdgpu_buffer_rsrc_t r2 = dpi_buffer_t(a.x2, (size_t)a.C2 * Vo, a.xb);
       int voff[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -392,7 +409,8 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
         wv = ok ? wraw : 0.f;
         const int cbase = c * (int)Vo;                      // host guarantees C2 * Vo * 4 < 2^31 (+ one channel group of slack)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = dpi_buffer_load(r2, voff[t] >= 0 ? (cbase + voff[t]) * 4 : -4);
+        for (int t = 0; t < NT; ++t)
+          b[t] = a.xb ? dpi_buffer_load_bf16(r2, voff[t] >= 0 ? cbase + voff[t] : -1) : dpi_buffer_load(r2, voff[t] >= 0 ? (cbase + voff[t]) * 4 : -4);
       };
       float b0[NT], b1[NT], w0v, w1v;
       load2(b0, w0v, 0);
@@ -418,13 +436,13 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
       const int co = n0 + 4 * lk + r;
       const bool cok = co < a.Cout;
       const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
-      float* __restrict__ yc = ybase + (size_t)(cok ? co : 0) * Vo + vbase;
+      float* __restrict__ yc = dpi_at(ybase, (size_t)(cok ? co : 0) * Vo + vbase, a.yb);
       double s = 0.0, q = 0.0;
       if (interior) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const float v = acc[t][r] + bv;
-          yc[(t / NH) * Wo + (t % NH) * 16] = v;
+          const float v = dpi_stored(acc[t][r] + bv, a.yb);        // statistics describe what is stored
+          dpi_st(yc, (t / NH) * Wo + (t % NH) * 16, v, a.yb);
           if (a.partials) { s += v; q += (double)v * v; }
         }
       } else {
@@ -432,8 +450,8 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
         for (int t = 0; t < NT; ++t) {
           const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
           if (cok && od < Do && oh < Ho && ow < Wo) {
-            const float v = acc[t][r] + bv;
-            yc[(t / NH) * Wo + (t % NH) * 16] = v;
+            const float v = dpi_stored(acc[t][r] + bv, a.yb);
+            dpi_st(yc, (t / NH) * Wo + (t % NH) * 16, v, a.yb);
             s += v;
             q += (double)v * v;
           }
@@ -485,6 +503,7 @@ struct BwMArgs {
   // rows — and the chunk's X halo rows — run back to back on ONE XCD and find them in its L2 instead of re-reading HBM
   // (measured before: 3.4 GB fetched per launch for 0.69 GB algorithmic on 25 -> 16).
   int ngroups, nchunks;
+  int xb, dyb;              // storage type of the tensor behind `x` (staged) and behind `dy` (the 16-row operand): 1 = bf16 (roles as AFTER a swap)
 };
 
 // TC != 0: the launch covers a final group that holds only TC real channels (Cin = 4m + 1: TC = 1) and computes just their
@@ -501,8 +520,10 @@ struct BwLds {
 // dY rows (fetch, transpose through LDS, 64 reads per wave and tile), the tile addressing and the two barriers are paid once per 896
 // MFMAs instead of once per 448, and a layer's dY is streamed half as often (70 KB of LDS: two workgroups per CU, which costs this
 // kernel nothing).  first_group: the first of the NG groups this workgroup owns (-1: blockIdx.y, or the XCD-aware 1-D order).
-template <int KD, int S, int NR, int NH, int TC, int NG = 1>
-__device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a, float* __restrict__ lds, float* __restrict__ dyl_all, int first_group = -1) {
+template <int KD, int S, int NR, int NH, int TC, int NG = 1, bool IOB = false>
+__device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a_in, float* __restrict__ lds, float* __restrict__ dyl_all, int first_group = -1) {
+  BwMArgs a = a_in;
+  if constexpr (!IOB) { a.xb = 0; a.dyb = 0; }       // (a template parameter for the same reason as in conv_mfma_kernel)
   static_assert(NG == 1 || TC == 0, "the column-trimmed tail is a single group");
 #ifdef DPI_TRACE
   const int trc = (blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 4) ? (int)blockIdx.x : -1;
@@ -549,7 +570,7 @@ __device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a, floa
     toff[t] = c * G::CS + kd * G::DS + kh * G::RS + kw;
   }
   const int lbase = wz * G::SD * G::DS + wh * S * G::RS + lk * S;
-  const __amdgpu_buffer_rsrc_t dyb = dpi_buffer(a.dy + (size_t)n0 * Vo, (size_t)min(16, a.Cout - n0) * Vo * sizeof(float));
+  const __amdgpu_buffer_rsrc_t dyb = dpi_buffer_t(dpi_at(a.dy, (size_t)n0 * Vo, a.dyb), (size_t)min(16, a.Cout - n0) * Vo, a.dyb);
 
   constexpr int NA = NG * NTQ;                 // accumulators / B operands per k-step
   f32x4 acc[NA];
@@ -570,8 +591,8 @@ __device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a, floa
   if (t_begin < t_end) {
     tile_origin(t_begin, od0, oh0, ow0);
     tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
-    stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
-    if constexpr (NG == 2) stage_load<G>(sr2, a.x, a.Cin, V, c0 + 4, goff);
+    stage_load<G>(sr, a.x, a.Cin, V, c0, goff, a.xb);
+    if constexpr (NG == 2) stage_load<G>(sr2, a.x, a.Cin, V, c0 + 4, goff, a.xb);
   }
   for (int tile = t_begin; tile < t_end; ++tile) {
     TRW();
@@ -593,7 +614,12 @@ __device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a, floa
 #pragma unroll
       for (int j = 0; j < JP; ++j) {
         const int p4 = 4 * (wp + 4 * j);
-        raw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyb, (row_ok && cow0 + p4 < Wo) ? (base + p4) * 4 : -16, 0, 0));
+        if (a.dyb) {        // four bf16 in one 8-byte piece
+          const dpi_u32x2v u = __builtin_bit_cast(dpi_u32x2v, __builtin_amdgcn_raw_buffer_load_b64(dyb, (row_ok && cow0 + p4 < Wo) ? (base + p4) * 2 : -8, 0, 0));
+          raw[j] = (f32x4){__builtin_bit_cast(float, u[0] << 16), __builtin_bit_cast(float, u[0] & 0xffff0000u),
+                           __builtin_bit_cast(float, u[1] << 16), __builtin_bit_cast(float, u[1] & 0xffff0000u)};
+        } else
+          raw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyb, (row_ok && cow0 + p4 < Wo) ? (base + p4) * 4 : -16, 0, 0));
       }
     };
     auto put_row = [&](const f32x4 (&raw)[JP]) {
@@ -619,8 +645,8 @@ __device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a, floa
     if (tile + 1 < t_end) {                                  // prefetch the next tile behind this tile's MFMAs
       tile_origin(tile + 1, od0, oh0, ow0);
       tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
-      stage_load<G>(sr, a.x, a.Cin, V, c0, goff);
-      if constexpr (NG == 2) stage_load<G>(sr2, a.x, a.Cin, V, c0 + 4, goff);
+      stage_load<G>(sr, a.x, a.Cin, V, c0, goff, a.xb);
+      if constexpr (NG == 2) stage_load<G>(sr2, a.x, a.Cin, V, c0 + 4, goff, a.xb);
     }
     TRW();
     // Software pipeline (as in the forward kernel): the B operands of step (hr, s + 1) and the A row of hr + 1 are requested
@@ -683,12 +709,12 @@ __device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a, floa
   }
 }
 
-template <int KD, int S, int NR, int NH, int TC = 0>
+template <int KD, int S, int NR, int NH, int TC = 0, bool IOB = false>
 __global__ __launch_bounds__(256) void conv_bwd_weight_mfma_kernel(BwMArgs a) {
   using L = BwLds<KD, S, NR, NH>;
   __shared__ __attribute__((aligned(16))) float lds[L::LDSF];
   __shared__ __attribute__((aligned(16))) float dyl[4 * 16 * L::DYRS];
-  conv_bwd_weight_mfma_body<KD, S, NR, NH, TC>(a, lds, dyl);
+  conv_bwd_weight_mfma_body<KD, S, NR, NH, TC, 1, IOB>(a, lds, dyl);
 }
 
 // Staged channel count 4m + 1 in ONE launch: the workgroups of the last group (blockIdx.y = gridDim.y - 1) run the column-trimmed
@@ -731,6 +757,7 @@ struct BwSArgs {
   int Cin, Cout;
   int D, H, W;
   int ntd, nth, ntw, ntiles, tiles_per_chunk;
+  int xb, dyb;              // storage type of x / dy: 1 = bf16
 };
 
 __global__ __launch_bounds__(256) void conv_bwd_weight_smallco_kernel(BwSArgs a) {
@@ -764,7 +791,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_smallco_kernel(BwSArgs a)
   __shared__ __attribute__((aligned(16))) float dyl[4][5 * DYRS];
   float* __restrict__ dyw = dyl[wid];
   for (int i = lane; i < 5 * DYRS; i += 64) dyw[i] = 0.f;
-  const __amdgpu_buffer_rsrc_t dyb = dpi_buffer(a.dy, (size_t)a.Cout * V * sizeof(float));   // Cout <= 5: host keeps 5*V*4 < 2^31
+  const __amdgpu_buffer_rsrc_t dyb = dpi_buffer_t(a.dy, (size_t)a.Cout * V, a.dyb);   // Cout <= 5: host keeps 5*V*4 < 2^31
   const int wch = lane >> 3, wp4 = 4 * (lane & 7);         // fetch mapping: channel, first voxel of the float4 piece
   const int boff = bok ? bco * DYRS + 4 + lk - bkw : 0;    // B operand: voxel 4s + lk - kw of channel co (index 0 is a zero)
 
@@ -795,9 +822,9 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_smallco_kernel(BwSArgs a)
   auto gload = [&]() {                                   // buffer loads: goff = -1 (outside the volume) -> 0; channels past
 #pragma unroll                                           // Cin re-read the last one (their rows of dW are never written)
     for (int c = 0; c < CB; ++c) {
-      const __amdgpu_buffer_rsrc_t r = dpi_buffer(a.x + (size_t)min(c0 + c, a.Cin - 1) * V, V * sizeof(float));
+      const __amdgpu_buffer_rsrc_t r = dpi_buffer_t(dpi_at(a.x, (size_t)min(c0 + c, a.Cin - 1) * V, a.xb), V, a.xb);
 #pragma unroll
-      for (int e = 0; e < E; ++e) sr[c][e] = dpi_buffer_load(r, goff[e] * 4);
+      for (int e = 0; e < E; ++e) sr[c][e] = a.xb ? dpi_buffer_load_bf16(r, goff[e]) : dpi_buffer_load(r, goff[e] * 4);
     }
   };
   int od0 = 0, oh0 = 0, ow0 = 0;
@@ -818,8 +845,13 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_smallco_kernel(BwSArgs a)
     auto load_raw = [&](int hr) {
       const int oh = coh0 + hr;
       const bool ok = wch < a.Cout && cod < a.D && oh < a.H && cow0 + wp4 < a.W;
-      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-          dyb, ok ? (wch * (int)V + (cod * a.H + oh) * a.W + cow0 + wp4) * 4 : -16, 0, 0));
+      const int el = wch * (int)V + (cod * a.H + oh) * a.W + cow0 + wp4;
+      if (a.dyb) {
+        const dpi_u32x2v u = __builtin_bit_cast(dpi_u32x2v, __builtin_amdgcn_raw_buffer_load_b64(dyb, ok ? el * 2 : -8, 0, 0));
+        return (f32x4){__builtin_bit_cast(float, u[0] << 16), __builtin_bit_cast(float, u[0] & 0xffff0000u),
+                       __builtin_bit_cast(float, u[1] << 16), __builtin_bit_cast(float, u[1] & 0xffff0000u)};
+      }
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyb, ok ? el * 4 : -16, 0, 0));
     };
     auto put_row = [&](f32x4 v) {
 #pragma unroll
@@ -886,6 +918,7 @@ struct BdS2Args {
   int D, H, W, Do, Ho, Wo;
   int ntd, nth, ntw;
   int accumulate;
+  int dyb, dxb;            // storage type of dy / dx: 1 = bf16
 };
 
 template <int KD>
@@ -938,9 +971,9 @@ __global__ __launch_bounds__(256) void conv_bwd_data_s2_mfma_kernel(BdS2Args a) 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       // channels past Cout re-read the last one: their weights are zero
-      const __amdgpu_buffer_rsrc_t r = dpi_buffer(a.dy + (size_t)min(c0 + c, a.Cout - 1) * Vo, Vo * sizeof(float));
+      const __amdgpu_buffer_rsrc_t r = dpi_buffer_t(dpi_at(a.dy, (size_t)min(c0 + c, a.Cout - 1) * Vo, a.dyb), Vo, a.dyb);
 #pragma unroll
-      for (int e = 0; e < E; ++e) sr[c][e] = dpi_buffer_load(r, goff[e] * 4);      // outside the tile / volume -> 0
+      for (int e = 0; e < E; ++e) sr[c][e] = a.dyb ? dpi_buffer_load_bf16(r, goff[e]) : dpi_buffer_load(r, goff[e] * 4);      // outside the tile / volume -> 0
     }
   };
   fetch(0);
@@ -993,8 +1026,8 @@ __global__ __launch_bounds__(256) void conv_bwd_data_s2_mfma_kernel(BdS2Args a) 
         for (int r = 0; r < 4; ++r) {
           const int ci = n0 + 4 * lk + r;
           if (ci < a.Cin) {
-            float* p = a.dx + (size_t)ci * V + ((size_t)id * a.H + ih) * a.W + iw;
-            *p = a.accumulate ? *p + acc[cls][row][r] : acc[cls][row][r];
+            const size_t o = (size_t)ci * V + ((size_t)id * a.H + ih) * a.W + iw;
+            dpi_st(a.dx, o, a.accumulate ? dpi_ld(a.dx, o, a.dxb) + acc[cls][row][r] : acc[cls][row][r], a.dxb);
           }
         }
       }
@@ -1007,7 +1040,7 @@ __global__ __launch_bounds__(256) void conv_bwd_data_s2_mfma_kernel(BdS2Args a) 
 // (b, co) — any partition into nblk blocks serves dpi_bn_finalize, which only sums over blocks.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, const float* __restrict__ bias,
                                                             float* __restrict__ y, int accumulate, double* __restrict__ partials,
-                                                            int Cout, size_t Vo, size_t per) {
+                                                            int Cout, size_t Vo, size_t per, bool yb) {
   const int lane = threadIdx.x & 63, co = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (co >= Cout) return;
   const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < Vo ? lo + per : Vo;
@@ -1017,8 +1050,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     float t = ws[(size_t)co * Vo + v];
     for (int sp = 1; sp < nsplit; ++sp) t += ws[((size_t)sp * Cout + co) * Vo + v];
     t += bv;
-    if (accumulate) t += y[(size_t)co * Vo + v];
-    y[(size_t)co * Vo + v] = t;
+    if (accumulate) t += dpi_ld(y, (size_t)co * Vo + v, yb);
+    t = dpi_stored(t, yb);
+    dpi_st(y, (size_t)co * Vo + v, t, yb);
     sum += t; sq += (double)t * t;
   }
   if (partials) {
@@ -1066,20 +1100,23 @@ int dpi_mfma_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth, i
   return *ntd * *nth * *ntw;
 }
 
-template <int KD, bool FLIP>
+template <int KD, bool FLIP, bool IOB = false>
 static void launch_variant(const MArgs& a, int nr, int nh, int stride, dim3 grid, hipStream_t st) {
+  if constexpr (!IOB) {
+    if (a.xb || a.yb) { launch_variant<KD, FLIP, true>(a, nr, nh, stride, grid, st); return; }
+  }
   if (stride == 2) {
     if constexpr (!FLIP) {
-      if (nh == 2) conv_mfma_kernel<KD, 2, 2, false, 2><<<grid, 256, 0, st>>>(a);
-      else conv_mfma_kernel<KD, 2, 1, false, 2><<<grid, 256, 0, st>>>(a);
+      if (nh == 2) conv_mfma_kernel<KD, 2, 2, false, 2, 2, false, false, IOB><<<grid, 256, 0, st>>>(a);
+      else conv_mfma_kernel<KD, 2, 1, false, 2, 2, false, false, IOB><<<grid, 256, 0, st>>>(a);
     }
     return;
   }
   const bool tailpack = (a.Cin & 3) == 1 && (a.Cin > 4 || a.Cin == 1);     // instantiated separately: the packed tail costs ~15 VGPRs
   if (nr == 4) {
     if constexpr (KD == 3) {
-      if (tailpack) conv_mfma_kernel<KD, 4, 2, FLIP, 1, 3, false, true><<<grid, 256, 0, st>>>(a);
-      else conv_mfma_kernel<KD, 4, 2, FLIP, 1, 3, false, false><<<grid, 256, 0, st>>>(a);
+      if (tailpack) conv_mfma_kernel<KD, 4, 2, FLIP, 1, 3, false, true, IOB><<<grid, 256, 0, st>>>(a);
+      else conv_mfma_kernel<KD, 4, 2, FLIP, 1, 3, false, false, IOB><<<grid, 256, 0, st>>>(a);
     }
     return;
   }
@@ -1088,15 +1125,15 @@ static void launch_variant(const MArgs& a, int nr, int nh, int stride, dim3 grid
     // tiles stay on its XCD; fewer tiles than that -> one tile per workgroup as before
     static const bool persist = getenv("DPI_NO_PERSIST") == nullptr;
     dim3 pg = grid;
-    if (a.Cin <= 8) conv_mfma_kernel<KD, 8, 2, FLIP, 1, 3><<<grid, 256, 0, st>>>(a);   // occupancy 3 beats persistence here (measured)
+    if (a.Cin <= 8) conv_mfma_kernel<KD, 8, 2, FLIP, 1, 3, false, false, IOB><<<grid, 256, 0, st>>>(a);   // occupancy 3 beats persistence here (measured)
     else {
       if (persist && grid.x > 512) pg.x = 512;        // 2 workgroups per CU (256 VGPRs)
-      if (tailpack) conv_mfma_kernel<KD, 8, 2, FLIP, 1, 2, true, true><<<pg, 256, 0, st>>>(a);
-      else conv_mfma_kernel<KD, 8, 2, FLIP, 1, 2, true, false><<<pg, 256, 0, st>>>(a);
+      if (tailpack) conv_mfma_kernel<KD, 8, 2, FLIP, 1, 2, true, true, IOB><<<pg, 256, 0, st>>>(a);
+      else conv_mfma_kernel<KD, 8, 2, FLIP, 1, 2, true, false, IOB><<<pg, 256, 0, st>>>(a);
     }
   }
-  else if (nh == 2) conv_mfma_kernel<KD, 2, 2, FLIP><<<grid, 256, 0, st>>>(a);
-  else conv_mfma_kernel<KD, 2, 1, FLIP><<<grid, 256, 0, st>>>(a);
+  else if (nh == 2) conv_mfma_kernel<KD, 2, 2, FLIP, 1, 2, false, false, IOB><<<grid, 256, 0, st>>>(a);
+  else conv_mfma_kernel<KD, 2, 1, FLIP, 1, 2, false, false, IOB><<<grid, 256, 0, st>>>(a);
 }
 
 #ifdef DPI_TRACE
@@ -1150,7 +1187,8 @@ int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain
   const int taps = d->kd * 9;
   const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
   const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
-  MArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, accumulate, 0, nullptr, nullptr, 0, 0, 0};
+  MArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, accumulate, 0, nullptr, nullptr, 0, 0, 0,
+          dpi_io_in(d, flip), dpi_io_out(d, flip)};
   int nr, nh;
   dpi_mfma_variant(d, cout, &nr, &nh);
   if (dpi_mfma_half_tile(d, flip)) nr = 4;
@@ -1164,13 +1202,14 @@ int dpi_conv_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain
     const size_t Vo = (size_t)Do * Ho * Wo;
     DPI_REQUIRE(ws_floats >= (size_t)nsplit * cout * Vo, "conv (split): workspace of %zu floats, need %zu", ws_floats, (size_t)nsplit * cout * Vo);
     a.split_cps = 4 * cdiv(cdiv(cin, 4), nsplit);
-    a.y = ws; a.bias = nullptr; a.partials = nullptr; a.accumulate = 0;
+    a.y = ws; a.bias = nullptr; a.partials = nullptr; a.accumulate = 0; a.yb = 0;
     grid.z = cdiv(cin, a.split_cps);                                // <= nsplit; every column owns at least one chunk
     const int nz = (int)grid.z;
     if (d->kd == 3) { if (flip) launch_variant<3, true>(a, nr, nh, d->stride, grid, st); else launch_variant<3, false>(a, nr, nh, d->stride, grid, st); }
     else { if (flip) launch_variant<1, true>(a, nr, nh, d->stride, grid, st); else launch_variant<1, false>(a, nr, nh, d->stride, grid, st); }
     if (int e = dpi_check_launch("conv_mfma (split)")) return e;
-    splitk_reduce_kernel<<<dim3(ntiles, cdiv(cout, 4)), 256, 0, st>>>(ws, nz, bias, y, accumulate, partials, cout, Vo, cdivz(Vo, (size_t)ntiles));
+    splitk_reduce_kernel<<<dim3(ntiles, cdiv(cout, 4)), 256, 0, st>>>(ws, nz, bias, y, accumulate, partials, cout, Vo, cdivz(Vo, (size_t)ntiles),
+                                                                      dpi_io_out(d, flip));
     return dpi_check_launch("splitk_reduce");
   }
   if (d->kd == 3) { if (flip) launch_variant<3, true>(a, nr, nh, d->stride, grid, st); else launch_variant<3, false>(a, nr, nh, d->stride, grid, st); }
@@ -1210,7 +1249,7 @@ static MfmaBwPlan mfma_bw_plan(const dpi_conv_desc* d, bool swap = false) {
     const bool s1k3 = d->stride == 1 && d->kd == 3;
     const int tailg = (s1k3 && (staged & 3) == 1) ? 1 : 0;
     p.nfull = groups - tailg;
-    p.npairs = (g_bw_pair && s1k3 && !g_bw_xcd_order && p.nfull >= 2) ? p.nfull / 2 : 0;
+    p.npairs = (g_bw_pair && s1k3 && !g_bw_xcd_order && p.nfull >= 2 && d->io == 0) ? p.nfull / 2 : 0;     // (bf16 tensors: the plain kernels only)
     if (g_bw_pair == 2) {                                      // restricted: long group loops at the two finest levels only
       int a_, b_, c_;
       if (p.nfull < 4 || dpi_mfma_tiles(d, 8, 2, &a_, &b_, &c_) < 1024) p.npairs = 0;
@@ -1247,10 +1286,12 @@ int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const f
                                  hipStream_t st) {
   const bool swap = dpi_conv_bwd_weight_mfma_swapped(d, chain);     // the chain can only be applied to the staged tensor
   const MfmaBwPlan p = mfma_bw_plan(d, swap);
-  BwMArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk, 0, 0, 0, p.nchunks};
+  BwMArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk, 0, 0, 0, p.nchunks,
+            (d->io & DPI_IO_X_BF16) != 0, (d->io & DPI_IO_DY_BF16) != 0};
   dim3 grid(p.nchunks, cdiv(d->Cin, 4), cdiv(d->Cout, 16));
   if (swap) {
     a.x = dy; a.chain = nullptr; a.dy = x; a.Cin = d->Cout; a.Cout = d->Cin; a.swap = 1;
+    a.xb = (d->io & DPI_IO_DY_BF16) != 0; a.dyb = (d->io & DPI_IO_X_BF16) != 0;
     grid = dim3(p.nchunks, cdiv(d->Cout, 4), cdiv(d->Cin, 16));
   }
   // (chunk, group) grid -> 1-D XCD-aware order (see BwMArgs::ngroups)
@@ -1259,7 +1300,26 @@ int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const f
     a.ngroups = (int)g.y;
     return dim3(8u * g.y * (unsigned)cdiv((int)g.x, 8), 1, g.z);
   };
-  if (p.npairs > 0) {
+  if (a.xb || a.dyb) {
+    // bf16 tensors: the IOB instantiations of the plain kernel (the full groups and, for a staged count of 4m + 1, the column-trimmed tail
+    // group as a second launch).  In bf16 precision mode this path serves the stride-2 layers and rows that are not whole float4
+    // (conv_bf16_bww.hip takes the rest).
+    a.ngroups = 0;
+    if (d->stride == 1 && d->kd == 3 && (a.Cin & 3) == 1) {
+      if (grid.y > 1) conv_bwd_weight_mfma_kernel<3, 1, 8, 2, 0, true><<<dim3(grid.x, grid.y - 1, grid.z), 256, 0, st>>>(a);
+      a.y0 = (int)grid.y - 1;
+      conv_bwd_weight_mfma_kernel<3, 1, 8, 2, 1, true><<<dim3(grid.x, 1, grid.z), 256, 0, st>>>(a);
+    } else if (d->stride == 1) {
+      if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 1, 8, 2, 0, true><<<grid, 256, 0, st>>>(a);
+      else conv_bwd_weight_mfma_kernel<1, 1, 8, 2, 0, true><<<grid, 256, 0, st>>>(a);
+    } else if (p.nh == 2) {
+      if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 2, 2, 2, 0, true><<<grid, 256, 0, st>>>(a);
+      else conv_bwd_weight_mfma_kernel<1, 2, 2, 2, 0, true><<<grid, 256, 0, st>>>(a);
+    } else {
+      if (d->kd == 3) conv_bwd_weight_mfma_kernel<3, 2, 2, 1, 0, true><<<grid, 256, 0, st>>>(a);
+      else conv_bwd_weight_mfma_kernel<1, 2, 2, 1, 0, true><<<grid, 256, 0, st>>>(a);
+    }
+  } else if (p.npairs > 0) {
     a.ngroups = 0;
     conv_bwd_weight_mfma_pair_kernel<3, 1, 8, 2><<<dim3(grid.x, p.ny, grid.z), 256, 0, st>>>(a, p.npairs, p.nfull);
   } else if (d->stride == 1 && d->kd == 3 && (a.Cin & 3) == 1) {
@@ -1301,7 +1361,7 @@ int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const f
 int dpi_conv_bwd_data_s2_mfma_run(const dpi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, hipStream_t st) {
   int Do, Ho, Wo;
   dpi_conv_out_dims(d, &Do, &Ho, &Wo);
-  BdS2Args a{dy, w, dx, d->Cin, d->Cout, d->D, d->H, d->W, Do, Ho, Wo, 0, 0, 0, accumulate};
+  BdS2Args a{dy, w, dx, d->Cin, d->Cout, d->D, d->H, d->W, Do, Ho, Wo, 0, 0, 0, accumulate, (d->io & DPI_IO_DY_BF16) != 0, (d->io & DPI_IO_DX_BF16) != 0};
   const int md = d->kd == 3 ? cdiv(d->D, 2) : d->D, mh = cdiv(d->H, 2), mw = cdiv(d->W, 2);
   a.ntd = md; a.nth = cdiv(mh, 8); a.ntw = cdiv(mw, 16);
   dim3 grid(a.ntd * a.nth * a.ntw, cdiv(d->Cin, 16));
@@ -1332,7 +1392,8 @@ size_t dpi_conv_bwd_weight_smallco_ws_floats(const dpi_conv_desc* d) {
 int dpi_conv_bwd_weight_smallco_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws,
                                     hipStream_t st) {
   const SmallBwPlan p = small_bw_plan(d);
-  BwSArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk};
+  BwSArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk,
+            (d->io & DPI_IO_X_BF16) != 0, (d->io & DPI_IO_DY_BF16) != 0};
   conv_bwd_weight_smallco_kernel<<<dim3(p.nchunks, cdiv(d->Cin, 6)), 256, 0, st>>>(a);
   if (int e = dpi_check_launch("conv_bwd_weight_smallco")) return e;
   const size_t per = (size_t)d->Cout * d->Cin * 27;

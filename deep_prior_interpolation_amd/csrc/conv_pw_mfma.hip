@@ -28,6 +28,7 @@ struct PwMArgs {
   long w_out_stride, w_in_stride;
   int accumulate;
   int gpb;                  // 64-voxel groups per workgroup: 16 (1024 voxels) or 4 (256 voxels, coarse levels)
+  int xb, yb;               // storage type of x / y in HBM: 1 = bf16 (dpi_conv_desc.io), 0 = fp32
 };
 
 // block = 4 waves = 1024 voxels (wave w takes 64-voxel groups w, w+4, w+8, w+12); MT cout tiles per block.
@@ -76,13 +77,13 @@ __global__ __launch_bounds__(256) void conv_pw_mfma_kernel(PwMArgs a) {
 #pragma unroll
       for (int p = 0; p < PF; ++p) {
         const int ci = min((cb + p) * 4 + lk, a.Cin - 1);       // past Cin: re-read the last channel, weights are zero
-        const float* __restrict__ xp = a.x + (size_t)ci * a.V;
+        const float* __restrict__ xp = dpi_at(a.x, (size_t)ci * a.V, a.xb);
         if (full4) {
-          const float4 f = *reinterpret_cast<const float4*>(xp + v0);
+          const float4 f = dpi_ld4(xp, v0, a.xb, false);
           b[p][0] = f.x; b[p][1] = f.y; b[p][2] = f.z; b[p][3] = f.w;
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const float v = xp[v0 + e < a.V ? v0 + e : 0]; b[p][e] = v0 + e < a.V ? v : 0.f; }
+          for (int e = 0; e < 4; ++e) { const float v = dpi_ld(xp, v0 + e < a.V ? v0 + e : 0, a.xb); b[p][e] = v0 + e < a.V ? v : 0.f; }
         }
       }
 #pragma unroll
@@ -120,24 +121,27 @@ __global__ __launch_bounds__(256) void conv_pw_mfma_kernel(PwMArgs a) {
         const int co = n0 + m * 16 + 4 * lk + r;
         if (co < a.Cout) {
           const float bv = a.bias ? a.bias[co] : 0.f;
-          float* yp = a.y + (size_t)co * a.V + v0;
+          float* yp = dpi_at(a.y, (size_t)co * a.V, a.yb);
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[m][e][r] + bv;
           if (vec && v0 + 3 < a.V) {
             if (a.accumulate) {
-              const float4 o = *reinterpret_cast<const float4*>(yp);
+              const float4 o = dpi_ld4(yp, v0, a.yb, false);
               v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
             }
-            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = dpi_stored(v[e], a.yb);          // statistics describe what is stored
+            dpi_st4(yp, v0, make_float4(v[0], v[1], v[2], v[3]), a.yb, false);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { ssum[m][r] += v[e]; qsum[m][r] += (double)v[e] * v[e]; }
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               if (v0 + e < a.V) {
-                if (a.accumulate) v[e] += yp[e];
-                yp[e] = v[e];
+                if (a.accumulate) v[e] += dpi_ld(yp, v0 + e, a.yb);
+                v[e] = dpi_stored(v[e], a.yb);
+                dpi_st(yp, v0 + e, v[e], a.yb);
                 ssum[m][r] += v[e]; qsum[m][r] += (double)v[e] * v[e];
               }
           }
@@ -173,6 +177,7 @@ struct PwBwArgs {
   int Cin, Cout;
   size_t V;
   size_t vox_per_chunk;     // multiple of 64
+  int xb, dyb;              // storage type of x / dy: 1 = bf16
 };
 
 template <int MT, int NT>   // MT cout tiles x NT cin tiles per block
@@ -198,9 +203,9 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_weight_mfma_kernel(PwBwArgs a
   const float* __restrict__ dyr[MT];
   const float* __restrict__ xr[NT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) dyr[m] = a.dy + (size_t)min(co0 + m * 16 + lj, a.Cout - 1) * a.V;
+  for (int m = 0; m < MT; ++m) dyr[m] = dpi_at(a.dy, (size_t)min(co0 + m * 16 + lj, a.Cout - 1) * a.V, a.dyb);
 #pragma unroll
-  for (int n = 0; n < NT; ++n) xr[n] = a.x + (size_t)min(ci0 + n * 16 + lj, a.Cin - 1) * a.V;
+  for (int n = 0; n < NT; ++n) xr[n] = dpi_at(a.x, (size_t)min(ci0 + n * 16 + lj, a.Cin - 1) * a.V, a.xb);
   const int mt_valid = min(MT, (a.Cout - co0 + 15) / 16), nt_valid = min(NT, (a.Cin - ci0 + 15) / 16);
   for (size_t g0 = vbeg + (size_t)wid * 64; g0 < vend; g0 += 256) {
     // element e = 4j + i of a lane is voxel g0 + 16j + 4lk + i: float4 j of the four lk lanes of a row is ONE 64-byte piece
@@ -209,26 +214,26 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_weight_mfma_kernel(PwBwArgs a
     auto vox = [&](int e) { return v0 + 16 * (e >> 2) + (e & 3); };
     const bool whole = vec && g0 + 63 < vend;
     float ga[MT][16], xb[NT][16];
-    auto load16 = [&](const float* __restrict__ p, float (&o)[16]) {
+    auto load16 = [&](const float* __restrict__ p, float (&o)[16], bool bf) {
       if (whole) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float4 f = *reinterpret_cast<const float4*>(p + v0 + 16 * j);
+          const float4 f = dpi_ld4(p, v0 + 16 * j, bf, false);
           o[4 * j] = f.x; o[4 * j + 1] = f.y; o[4 * j + 2] = f.z; o[4 * j + 3] = f.w;
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { const float v = p[vox(e) < vend ? vox(e) : vbeg]; o[e] = vox(e) < vend ? v : 0.f; }
+        for (int e = 0; e < 16; ++e) { const float v = dpi_ld(p, vox(e) < vend ? vox(e) : vbeg, bf); o[e] = vox(e) < vend ? v : 0.f; }
       }
     };
     // 16-channel tiles that lie entirely past Cout / Cin (e.g. Cin = 67: the second 64-channel block holds 3 channels)
     // are skipped — block-uniform tests; without them those tiles re-read the clamped last channel 16 times over
 #pragma unroll
     for (int m = 0; m < MT; ++m)
-      if (m < mt_valid) load16(dyr[m], ga[m]);
+      if (m < mt_valid) load16(dyr[m], ga[m], a.dyb);
 #pragma unroll
     for (int n = 0; n < NT; ++n)
-      if (n < nt_valid) load16(xr[n], xb[n]);
+      if (n < nt_valid) load16(xr[n], xb[n], a.xb);
     if (a.chain) {
 #pragma unroll
       for (int n = 0; n < NT; ++n)
@@ -318,7 +323,7 @@ int dpi_conv_pw_mfma_run(const dpi_conv_desc* d, const float* x, const float* ch
   const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
   const long w_out = flip ? 1 : (long)d->Cin, w_in = flip ? (long)d->Cin : 1;
   int vpb, mt;
-  PwMArgs a{x, chain, w, bias, y, partials, cin, cout, (size_t)d->D * d->H * d->W, w_out, w_in, accumulate, 0};
+  PwMArgs a{x, chain, w, bias, y, partials, cin, cout, (size_t)d->D * d->H * d->W, w_out, w_in, accumulate, 0, dpi_io_in(d, flip), dpi_io_out(d, flip)};
   dpi_conv_pw_mfma_plan(a.V, cout, &vpb, &mt);
   a.gpb = vpb / 64;
   const unsigned gx = (unsigned)cdivz(a.V, vpb);
@@ -341,7 +346,7 @@ size_t dpi_conv_pw_bwd_weight_mfma_ws_floats(const dpi_conv_desc* d) {
 int dpi_conv_pw_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws,
                                     hipStream_t st) {
   const PwBwPlan p = pw_bw_plan(d);
-  PwBwArgs a{x, chain, dy, ws, d->Cin, d->Cout, (size_t)d->D * d->H * d->W, p.vox_per_chunk};
+  PwBwArgs a{x, chain, dy, ws, d->Cin, d->Cout, (size_t)d->D * d->H * d->W, p.vox_per_chunk, (d->io & DPI_IO_X_BF16) != 0, (d->io & DPI_IO_DY_BF16) != 0};
   dim3 grid(p.nchunks, cdiv(d->Cin, 16 * p.nt), cdiv(d->Cout, 16 * p.mt));
   if (p.mt == 1) {
     if (p.nt == 1) conv_pw_bwd_weight_mfma_kernel<1, 1><<<grid, 256, 0, st>>>(a);

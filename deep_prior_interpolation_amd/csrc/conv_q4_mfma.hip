@@ -576,6 +576,7 @@ extern "C" void dpi_set_q4(int on, int ck) {
 // enough tiles to give every CU one.
 bool dpi_conv_q4_usable(const dpi_conv_desc* d, bool flip) {
   if (!g_q4 || d->k != 3 || d->kd != 3 || d->stride != 1) return false;
+  if (dpi_io_in(d, flip) || dpi_io_out(d, flip)) return false;      // fp32 tensors only: bf16 storage takes the bf16 / 16x16x4 kernels (ABI 400)
   const int cout = flip ? d->Cin : d->Cout;
   if (cout > 8 || (d->W & 3)) return false;
   if (g_q4 == 2) return true;

@@ -31,23 +31,23 @@ __device__ __forceinline__ void st4(float* p, float4 v, bool nt) {
 
 // ---- per-channel {sum, sum^2} of T(x) ------------------------------------------------------------------
 __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, const float* __restrict__ chain,
-                                                            int C, size_t V, int nblk, double* __restrict__ partials) {
+                                                            int C, size_t V, int nblk, double* __restrict__ partials, bool xb = false) {
   const bool nt = (size_t)gridDim.y * V >= kNtMinFloats;
   const int c = blockIdx.y, b = blockIdx.x;
   const size_t span = stat_span(V, nblk);
   const size_t beg = (size_t)b * span, end = beg + span < V ? beg + span : V;
-  const float* __restrict__ xc = x + (size_t)c * V;
+  const float* __restrict__ xc = dpi_at(x, (size_t)c * V, xb);
   const Chain t = load_chain(chain, c);
   double s = 0.0, q = 0.0;
   const bool vec = (V & 3) == 0;
   for (size_t i = beg + (size_t)threadIdx.x * 4; i < end; i += 1024) {
     float v[4];
     if (vec) {
-      const float4 f = ld4(xc + i, nt);
+      const float4 f = dpi_ld4(xc, i, xb, nt);
       v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = i + k < end ? xc[i + k] : 0.f;
+      for (int k = 0; k < 4; ++k) v[k] = i + k < end ? dpi_ld(xc, i + k, xb) : 0.f;
     }
     float ls = 0.f;
     double lq = 0.0;
@@ -123,20 +123,20 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
 }
 
 __global__ __launch_bounds__(256) void chain_apply_kernel(const float* __restrict__ x, const float* __restrict__ chain, size_t V,
-                                                          float* __restrict__ y) {
+                                                          float* __restrict__ y, bool xb = false, bool yb = false) {
   const bool nt = (size_t)gridDim.y * V >= kNtMinFloats;
   const int c = blockIdx.y;
   const Chain t = load_chain(chain, c);
-  const float* __restrict__ xc = x + (size_t)c * V;
-  float* __restrict__ yc = y + (size_t)c * V;
+  const float* __restrict__ xc = dpi_at(x, (size_t)c * V, xb);
+  float* __restrict__ yc = dpi_at(y, (size_t)c * V, yb);
   const bool vec = (V & 3) == 0;
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < V; i += (size_t)gridDim.x * 1024) {
     if (vec) {
-      float4 f = ld4(xc + i, nt);
+      float4 f = dpi_ld4(xc, i, xb, nt);
       f.x = apply_chain(t, f.x); f.y = apply_chain(t, f.y); f.z = apply_chain(t, f.z); f.w = apply_chain(t, f.w);
-      st4(yc + i, f, nt);
+      dpi_st4(yc, i, f, yb, nt);
     } else {
-      for (int k = 0; k < 4 && i + k < V; ++k) yc[i + k] = apply_chain(t, xc[i + k]);
+      for (int k = 0; k < 4 && i + k < V; ++k) dpi_st(yc, i + k, apply_chain(t, dpi_ld(xc, i + k, xb)), yb);
     }
   }
 }
@@ -176,26 +176,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ in_chain,
                                                             float pre, float post, int C, size_t V, int nblk,
-                                                            double* __restrict__ partials) {
+                                                            double* __restrict__ partials, bool fb = false, bool gb = false) {
+  // fb: the forward tensor x is bf16; gb: the gradient tensor dy is bf16 (all BatchNorm-backward kernels below alike)
   const bool nt = (size_t)gridDim.y * V >= kNtMinFloats;
   const int c = blockIdx.y, b = blockIdx.x;
   const size_t span = stat_span(V, nblk);
   const size_t beg = (size_t)b * span, end = beg + span < V ? beg + span : V;
   const BnBwd k = bn_bwd_consts(mean_invstd, gamma, beta, in_chain, pre, post, C, c);
-  const float* __restrict__ xc = x + (size_t)c * V;
-  const float* __restrict__ gc = dy + (size_t)c * V;
+  const float* __restrict__ xc = dpi_at(x, (size_t)c * V, fb);
+  const float* __restrict__ gc = dpi_at(dy, (size_t)c * V, gb);
   double s = 0.0, q = 0.0;
   const bool vec = (V & 3) == 0;
   for (size_t i = beg + (size_t)threadIdx.x * 4; i < end; i += 1024) {
     float xv[4], gv[4];
     if (vec) {
-      const float4 f = ld4(xc + i, nt);
-      const float4 g = ld4(gc + i, nt);
+      const float4 f = dpi_ld4(xc, i, fb, nt);
+      const float4 g = dpi_ld4(gc, i, gb, nt);
       xv[0] = f.x; xv[1] = f.y; xv[2] = f.z; xv[3] = f.w;
       gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { xv[j] = i + j < end ? xc[i + j] : 0.f; gv[j] = i + j < end ? gc[i + j] : 0.f; }
+      for (int j = 0; j < 4; ++j) { xv[j] = i + j < end ? dpi_ld(xc, i + j, fb) : 0.f; gv[j] = i + j < end ? dpi_ld(gc, i + j, gb) : 0.f; }
     }
     float ls = 0.f, lq = 0.f;
 #pragma unroll
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ beta, const float* __restrict__ in_chain,
                                                            float pre, float post, const double* __restrict__ partials, int nblk, int C, size_t V,
                                                            float* __restrict__ dx, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta) {
+                                                           float* __restrict__ dbeta, bool fb = false, bool gb = false) {
   const bool nt = (size_t)gridDim.y * V >= kNtMinFloats;
   const int c = blockIdx.y;
   __shared__ double tot[2];
@@ -242,9 +243,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     if (dgamma) dgamma[c] = (float)tot[1];
     if (dbeta) dbeta[c] = (float)tot[0];
   }
-  const float* __restrict__ xc = x + (size_t)c * V;
-  const float* __restrict__ gc = dy + (size_t)c * V;
-  float* __restrict__ oc = dx + (size_t)c * V;
+  const float* __restrict__ xc = dpi_at(x, (size_t)c * V, fb);
+  const float* __restrict__ gc = dpi_at(dy, (size_t)c * V, gb);
+  float* __restrict__ oc = dpi_at(dx, (size_t)c * V, gb);
   const bool vec = (V & 3) == 0;
   auto one = [&](float xv, float gv) {
     float xh, g;
@@ -254,11 +255,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   };
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < V; i += (size_t)gridDim.x * 1024) {
     if (vec) {
-      const float4 f = ld4(xc + i, nt);
-      const float4 g = ld4(gc + i, nt);
-      st4(oc + i, make_float4(one(f.x, g.x), one(f.y, g.y), one(f.z, g.z), one(f.w, g.w)), nt);
+      const float4 f = dpi_ld4(xc, i, fb, nt);
+      const float4 g = dpi_ld4(gc, i, gb, nt);
+      dpi_st4(oc, i, make_float4(one(f.x, g.x), one(f.y, g.y), one(f.z, g.z), one(f.w, g.w)), gb, nt);
     } else {
-      for (int j = 0; j < 4 && i + j < V; ++j) oc[i + j] = one(xc[i + j], gc[i + j]);
+      for (int j = 0; j < 4 && i + j < V; ++j) dpi_st(oc, i + j, one(dpi_ld(xc, i + j, fb), dpi_ld(gc, i + j, gb)), gb);
     }
   }
 }
@@ -267,42 +268,42 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 __global__ __launch_bounds__(256) void chain_add_stats_kernel(const float* __restrict__ a, const float* __restrict__ chain_a,
                                                               const float* __restrict__ b, const float* __restrict__ chain_b, int C,
                                                               size_t V, int nblk, float slope, float* __restrict__ t,
-                                                              double* __restrict__ partials) {
+                                                              double* __restrict__ partials, bool fb = false) {
   const bool nt = (size_t)gridDim.y * V >= kNtMinFloats;
   const int c = blockIdx.y, blk = blockIdx.x;
   const size_t span = stat_span(V, nblk);
   const size_t beg = (size_t)blk * span, end = beg + span < V ? beg + span : V;
   const Chain ta = load_chain(chain_a, c), tb = load_chain(chain_b, c);
-  const float* __restrict__ ac = a + (size_t)c * V;
-  const float* __restrict__ bc = b + (size_t)c * V;
-  float* __restrict__ tc = t + (size_t)c * V;
+  const float* __restrict__ ac = dpi_at(a, (size_t)c * V, fb);
+  const float* __restrict__ bc = dpi_at(b, (size_t)c * V, fb);
+  float* __restrict__ tc = dpi_at(t, (size_t)c * V, fb);
   double s = 0.0, q = 0.0;
   const bool vec = (V & 3) == 0;
   for (size_t i = beg + (size_t)threadIdx.x * 4; i < end; i += 1024) {
     float av[4], bv[4], tv[4];
     if (vec) {
-      const float4 f = ld4(ac + i, nt);
-      const float4 g = ld4(bc + i, nt);
+      const float4 f = dpi_ld4(ac, i, fb, nt);
+      const float4 g = dpi_ld4(bc, i, fb, nt);
       av[0] = f.x; av[1] = f.y; av[2] = f.z; av[3] = f.w;
       bv[0] = g.x; bv[1] = g.y; bv[2] = g.z; bv[3] = g.w;
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { av[j] = i + j < end ? ac[i + j] : 0.f; bv[j] = i + j < end ? bc[i + j] : 0.f; }
+      for (int j = 0; j < 4; ++j) { av[j] = i + j < end ? dpi_ld(ac, i + j, fb) : 0.f; bv[j] = i + j < end ? dpi_ld(bc, i + j, fb) : 0.f; }
     }
     float ls = 0.f;
     double lq = 0.0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      tv[j] = apply_chain(ta, av[j]) + apply_chain(tb, bv[j]);
+      tv[j] = dpi_stored(apply_chain(ta, av[j]) + apply_chain(tb, bv[j]), fb);    // the statistics describe the stored t
       if (i + j < end) {
         const float y = tv[j] > 0.f ? tv[j] : tv[j] * slope;
         ls += y;
         lq += (double)y * y;
       }
     }
-    if (vec) st4(tc + i, make_float4(tv[0], tv[1], tv[2], tv[3]), nt);
+    if (vec) dpi_st4(tc, i, make_float4(tv[0], tv[1], tv[2], tv[3]), fb, nt);
     else
-      for (int j = 0; j < 4 && i + j < end; ++j) tc[i + j] = tv[j];
+      for (int j = 0; j < 4 && i + j < end; ++j) dpi_st(tc, i + j, tv[j], fb);
     s += ls; q += lq;
   }
   __shared__ double sh[8];
@@ -332,7 +333,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fork_kernel(const float* __r
                                                                 const float* __restrict__ beta, const float* __restrict__ in_chain,
                                                                 float pre, float post, const double* __restrict__ partials, int nblk_in,
                                                                 int C, size_t V, int nblk, float* __restrict__ dx,
-                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, BnFork fa, BnFork fb) {
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, BnFork fa, BnFork fb,
+                                                                bool tb = false, bool gb = false) {      // tb: forward tensors (x, fa.x, fb.x) bf16; gb: dy, dx bf16
   const bool nt = (size_t)gridDim.y * V >= kNtMinFloats;
   const int c = blockIdx.y, b = blockIdx.x;
   __shared__ double tot[2];
@@ -357,28 +359,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fork_kernel(const float* __r
   const BnBwd kb = fb.x ? bn_bwd_consts(fb.mean_invstd, fb.gamma, fb.beta, fb.in_chain, 1.f, fb.post, C, c) : k;
   const size_t span = stat_span(V, nblk);
   const size_t beg = (size_t)b * span, end = beg + span < V ? beg + span : V;
-  const float* __restrict__ xc = x + (size_t)c * V;
-  const float* __restrict__ gc = dy + (size_t)c * V;
-  const float* __restrict__ xa = fa.x ? fa.x + (size_t)c * V : xc;
-  const float* __restrict__ xb = fb.x ? fb.x + (size_t)c * V : xc;
-  float* __restrict__ oc = dx + (size_t)c * V;
+  const float* __restrict__ xc = dpi_at(x, (size_t)c * V, tb);
+  const float* __restrict__ gc = dpi_at(dy, (size_t)c * V, gb);
+  const float* __restrict__ xa = fa.x ? dpi_at(fa.x, (size_t)c * V, tb) : xc;
+  const float* __restrict__ xb = fb.x ? dpi_at(fb.x, (size_t)c * V, tb) : xc;
+  float* __restrict__ oc = dpi_at(dx, (size_t)c * V, gb);
   double sa = 0.0, qa = 0.0, sb = 0.0, qb = 0.0;
   const bool vec = (V & 3) == 0;
   for (size_t i = beg + (size_t)threadIdx.x * 4; i < end; i += 1024) {
     float xv[4], gv[4], av[4], bv[4], o[4];
     if (vec) {
-      const float4 f = ld4(xc + i, nt);
-      const float4 g = ld4(gc + i, nt);
+      const float4 f = dpi_ld4(xc, i, tb, nt);
+      const float4 g = dpi_ld4(gc, i, gb, nt);
       xv[0] = f.x; xv[1] = f.y; xv[2] = f.z; xv[3] = f.w;
       gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
-      if (fa.x) { const float4 t = ld4(xa + i, nt); av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w; }
-      if (fb.x) { const float4 t = ld4(xb + i, nt); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
+      if (fa.x) { const float4 t = dpi_ld4(xa, i, tb, nt); av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w; }
+      if (fb.x) { const float4 t = dpi_ld4(xb, i, tb, nt); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const bool in = i + j < end;
-        xv[j] = in ? xc[i + j] : 0.f; gv[j] = in ? gc[i + j] : 0.f;
-        av[j] = (in && fa.x) ? xa[i + j] : 0.f; bv[j] = (in && fb.x) ? xb[i + j] : 0.f;
+        xv[j] = in ? dpi_ld(xc, i + j, tb) : 0.f; gv[j] = in ? dpi_ld(gc, i + j, gb) : 0.f;
+        av[j] = (in && fa.x) ? dpi_ld(xa, i + j, tb) : 0.f; bv[j] = (in && fb.x) ? dpi_ld(xb, i + j, tb) : 0.f;
       }
     }
     float lsa = 0.f, lqa = 0.f, lsb = 0.f, lqb = 0.f;
@@ -387,15 +389,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fork_kernel(const float* __r
       float xh, g;
       bn_bwd_elem(k, xv[j], gv[j], xh, g);
       const float du = k.a * (g - k1 - xh * k2);
-      o[j] = (k.pre == 1.f || xv[j] > 0.f) ? du : du * k.pre;
+      o[j] = dpi_stored((k.pre == 1.f || xv[j] > 0.f) ? du : du * k.pre, gb);     // the follow-up partials describe the stored dx
       if (i + j < end) {
         if (fa.x) { float h, ga_; bn_bwd_elem(ka, av[j], o[j], h, ga_); lsa += ga_; lqa = fmaf(ga_, h, lqa); }
         if (fb.x) { float h, gb_; bn_bwd_elem(kb, bv[j], o[j], h, gb_); lsb += gb_; lqb = fmaf(gb_, h, lqb); }
       }
     }
-    if (vec) st4(oc + i, make_float4(o[0], o[1], o[2], o[3]), nt);
+    if (vec) dpi_st4(oc, i, make_float4(o[0], o[1], o[2], o[3]), gb, nt);
     else
-      for (int j = 0; j < 4 && i + j < end; ++j) oc[i + j] = o[j];
+      for (int j = 0; j < 4 && i + j < end; ++j) dpi_st(oc, i + j, o[j], gb);
     sa += lsa; qa += lqa; sb += lsb; qb += lqb;
   }
   __shared__ double sh[16];
@@ -425,7 +427,7 @@ struct BnSide {
 __global__ __launch_bounds__(256) void bn_bwd_apply_dual_kernel(const float* __restrict__ dy, BnSide A, BnSide B, int nblk_in, int C, size_t V,
                                                                 int nblk, int f_lo, int f_hi, const float* __restrict__ f_mi,
                                                                 const float* __restrict__ f_gamma, const float* __restrict__ f_beta,
-                                                                float f_post, double* __restrict__ f_partials) {
+                                                                float f_post, double* __restrict__ f_partials, bool tb = false, bool gb = false) {
   const bool nt = (size_t)gridDim.y * V >= kNtMinFloats;
   const int c = blockIdx.y, b = blockIdx.x;
   __shared__ double tot[4];
@@ -454,19 +456,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dual_kernel(const float* __r
   const BnBwd kf = forked ? bn_bwd_consts(f_mi, f_gamma, f_beta, nullptr, 1.f, f_post, fC, fc) : ka;
   const size_t span = stat_span(V, nblk);
   const size_t beg = (size_t)b * span, end = beg + span < V ? beg + span : V;
-  const float* __restrict__ gc = dy + (size_t)c * V;
-  const float* __restrict__ xa = A.x + (size_t)c * V;
-  const float* __restrict__ xb = B.x + (size_t)c * V;
-  float* __restrict__ oa = A.dx + (size_t)c * V;
-  float* __restrict__ ob = B.dx + (size_t)c * V;
+  const float* __restrict__ gc = dpi_at(dy, (size_t)c * V, gb);
+  const float* __restrict__ xa = dpi_at(A.x, (size_t)c * V, tb);
+  const float* __restrict__ xb = dpi_at(B.x, (size_t)c * V, tb);
+  float* __restrict__ oa = dpi_at(A.dx, (size_t)c * V, gb);
+  float* __restrict__ ob = dpi_at(B.dx, (size_t)c * V, gb);
   double sf = 0.0, qf = 0.0;
   const bool vec = (V & 3) == 0;
   for (size_t i = beg + (size_t)threadIdx.x * 4; i < end; i += 1024) {
     float gv[4], av[4], bv[4], ra[4], rb[4];
     if (vec) {
-      const float4 g = ld4(gc + i, nt);
-      const float4 t = ld4(xa + i, nt);
-      const float4 u = ld4(xb + i, nt);
+      const float4 g = dpi_ld4(gc, i, gb, nt);
+      const float4 t = dpi_ld4(xa, i, tb, nt);
+      const float4 u = dpi_ld4(xb, i, tb, nt);
       gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
       av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
       bv[0] = u.x; bv[1] = u.y; bv[2] = u.z; bv[3] = u.w;
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dual_kernel(const float* __r
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const bool in = i + j < end;
-        gv[j] = in ? gc[i + j] : 0.f; av[j] = in ? xa[i + j] : 0.f; bv[j] = in ? xb[i + j] : 0.f;
+        gv[j] = in ? dpi_ld(gc, i + j, gb) : 0.f; av[j] = in ? dpi_ld(xa, i + j, tb) : 0.f; bv[j] = in ? dpi_ld(xb, i + j, tb) : 0.f;
       }
     }
     float lsf = 0.f, lqf = 0.f;
@@ -484,14 +486,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dual_kernel(const float* __r
       bn_bwd_elem(ka, av[j], gv[j], xh, g);
       ra[j] = ka.a * (g - a1 - xh * a2);
       bn_bwd_elem(kb, bv[j], gv[j], xh, g);
-      rb[j] = kb.a * (g - b1 - xh * b2);
+      rb[j] = dpi_stored(kb.a * (g - b1 - xh * b2), gb);          // the fork's partials describe the stored dxb
       if (forked && i + j < end) { float h, gf_; bn_bwd_elem(kf, bv[j], rb[j], h, gf_); lsf += gf_; lqf = fmaf(gf_, h, lqf); }
     }
     if (vec) {
-      st4(oa + i, make_float4(ra[0], ra[1], ra[2], ra[3]), nt);
-      st4(ob + i, make_float4(rb[0], rb[1], rb[2], rb[3]), nt);
+      dpi_st4(oa, i, make_float4(ra[0], ra[1], ra[2], ra[3]), gb, nt);
+      dpi_st4(ob, i, make_float4(rb[0], rb[1], rb[2], rb[3]), gb, nt);
     } else {
-      for (int j = 0; j < 4 && i + j < end; ++j) { oa[i + j] = ra[j]; ob[i + j] = rb[j]; }
+      for (int j = 0; j < 4 && i + j < end; ++j) { dpi_st(oa, i + j, ra[j], gb); dpi_st(ob, i + j, rb[j], gb); }
     }
     sf += lsf; qf += lqf;
   }
@@ -597,31 +599,31 @@ __device__ __forceinline__ void lin_src(int o, int n, int& i0, int& i1, float& w
 
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, const float* __restrict__ chain, int D, int H,
                                                            int W, int Do, int Ho, int Wo, int linear, int scale_d,
-                                                           float* __restrict__ y) {
+                                                           float* __restrict__ y, bool xb = false, bool yb = false) {
   const int c = blockIdx.y;
   const size_t Vo = (size_t)Do * Ho * Wo, V = (size_t)D * H * W;
   const Chain t = load_chain(chain, c);
-  const float* __restrict__ xc = x + (size_t)c * V;
-  float* __restrict__ yc = y + (size_t)c * Vo;
+  const float* __restrict__ xc = dpi_at(x, (size_t)c * V, xb);
+  float* __restrict__ yc = dpi_at(y, (size_t)c * Vo, yb);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < Vo; i += (size_t)gridDim.x * 256) {
     const int ow = i % Wo, oh = (i / Wo) % Ho, od = i / ((size_t)Wo * Ho);
     float r;
     if (!linear) {
       const int id = scale_d ? od >> 1 : od;
-      r = apply_chain(t, xc[((size_t)id * H + (oh >> 1)) * W + (ow >> 1)]);
+      r = apply_chain(t, dpi_ld(xc, ((size_t)id * H + (oh >> 1)) * W + (ow >> 1), xb));
     } else {
       int d0, d1, h0, h1, w0, w1;
       float a0, a1, b0, b1, c0, c1;
       if (scale_d) lin_src(od, D, d0, d1, a0, a1); else { d0 = d1 = od; a0 = 1.f; a1 = 0.f; }
       lin_src(oh, H, h0, h1, b0, b1);
       lin_src(ow, W, w0, w1, c0, c1);
-      auto at = [&](int d, int h, int w) { return apply_chain(t, xc[((size_t)d * H + h) * W + w]); };
+      auto at = [&](int d, int h, int w) { return apply_chain(t, dpi_ld(xc, ((size_t)d * H + h) * W + w, xb)); };
       const float p0 = b0 * (c0 * at(d0, h0, w0) + c1 * at(d0, h0, w1)) + b1 * (c0 * at(d0, h1, w0) + c1 * at(d0, h1, w1));
       r = a0 * p0;
       if (scale_d)
         r += a1 * (b0 * (c0 * at(d1, h0, w0) + c1 * at(d1, h0, w1)) + b1 * (c0 * at(d1, h1, w0) + c1 * at(d1, h1, w1)));
     }
-    yc[i] = r;
+    dpi_st(yc, i, r, yb);
   }
 }
 
@@ -633,11 +635,11 @@ __device__ __forceinline__ float lin_wt(int o, int i, int n) {
 }
 
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, int D, int H, int W, int Do, int Ho, int Wo,
-                                                           int linear, int scale_d, float* __restrict__ dx) {
+                                                           int linear, int scale_d, float* __restrict__ dx, bool gb = false) {
   const int c = blockIdx.y;
   const size_t Vo = (size_t)Do * Ho * Wo, V = (size_t)D * H * W;
-  const float* __restrict__ gc = dy + (size_t)c * Vo;
-  float* __restrict__ oc = dx + (size_t)c * V;
+  const float* __restrict__ gc = dpi_at(dy, (size_t)c * Vo, gb);
+  float* __restrict__ oc = dpi_at(dx, (size_t)c * V, gb);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
     const int iw = i % W, ih = (i / W) % H, id = i / ((size_t)W * H);
     float acc = 0.f;
@@ -645,7 +647,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
       const int dlo = scale_d ? 2 * id : id, dhi = scale_d ? 2 * id + 1 : id;
       for (int od = dlo; od <= dhi && od < Do; ++od)
         for (int oh = 2 * ih; oh <= 2 * ih + 1 && oh < Ho; ++oh)
-          for (int ow = 2 * iw; ow <= 2 * iw + 1 && ow < Wo; ++ow) acc += gc[((size_t)od * Ho + oh) * Wo + ow];
+          for (int ow = 2 * iw; ow <= 2 * iw + 1 && ow < Wo; ++ow) acc += dpi_ld(gc, ((size_t)od * Ho + oh) * Wo + ow, gb);
     } else {
       const int dlo = scale_d ? max(2 * id - 1, 0) : id, dhi = scale_d ? min(2 * id + 2, Do - 1) : id;
       for (int od = dlo; od <= dhi; ++od) {
@@ -656,12 +658,12 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
           if (wh == 0.f) continue;
           for (int ow = max(2 * iw - 1, 0); ow <= min(2 * iw + 2, Wo - 1); ++ow) {
             const float ww = lin_wt(ow, iw, W);
-            if (ww != 0.f) acc = fmaf(wd * wh * ww, gc[((size_t)od * Ho + oh) * Wo + ow], acc);
+            if (ww != 0.f) acc = fmaf(wd * wh * ww, dpi_ld(gc, ((size_t)od * Ho + oh) * Wo + ow, gb), acc);
           }
         }
       }
     }
-    oc[i] = acc;
+    dpi_st(oc, i, acc, gb);
   }
 }
 
@@ -670,12 +672,13 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
 //   out[2i] = .25 in[i-1] + .75 in[i],  out[2i+1] = .75 in[i] + .25 in[i+1]   per axis (27 loads for 8 outputs)
 template <bool SCALE_D>
 __global__ __launch_bounds__(256) void upsample_lin_fwd_cube_kernel(const float* __restrict__ x, const float* __restrict__ chain, int D, int H,
-                                                                    int W, int Do, int Ho, int Wo, float* __restrict__ y) {
+                                                                    int W, int Do, int Ho, int Wo, float* __restrict__ y, bool xb = false,
+                                                                    bool yb = false) {
   const int c = blockIdx.y;
   const size_t V = (size_t)D * H * W, Vo = (size_t)Do * Ho * Wo;
   const Chain t = load_chain(chain, c);
-  const float* __restrict__ xc = x + (size_t)c * V;
-  float* __restrict__ yc = y + (size_t)c * Vo;
+  const float* __restrict__ xc = dpi_at(x, (size_t)c * V, xb);
+  float* __restrict__ yc = dpi_at(y, (size_t)c * Vo, yb);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
     const int w = i % W, h = (i / W) % H, d = i / ((size_t)W * H);
     const int wm = max(w - 1, 0), wp = min(w + 1, W - 1), hm = max(h - 1, 0), hp = min(h + 1, H - 1);
@@ -687,8 +690,9 @@ __global__ __launch_bounds__(256) void upsample_lin_fwd_cube_kernel(const float*
     for (int a = 0; a < (SCALE_D ? 3 : 1); ++a)
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
-        const float* row = xc + ((size_t)ds_[SCALE_D ? a : 1] * H + hs_[b]) * W;
-        const float v0 = apply_chain(t, row[ws_[0]]), v1 = apply_chain(t, row[ws_[1]]), v2 = apply_chain(t, row[ws_[2]]);
+        const size_t row = ((size_t)ds_[SCALE_D ? a : 1] * H + hs_[b]) * W;
+        const float v0 = apply_chain(t, dpi_ld(xc, row + ws_[0], xb)), v1 = apply_chain(t, dpi_ld(xc, row + ws_[1], xb)),
+                    v2 = apply_chain(t, dpi_ld(xc, row + ws_[2], xb));
         lo[a][b] = .25f * v0 + .75f * v1;
         hi[a][b] = .75f * v1 + .25f * v2;
       }
@@ -713,9 +717,13 @@ __global__ __launch_bounds__(256) void upsample_lin_fwd_cube_kernel(const float*
         } else {
           hcomb(0, r0, r1);
         }
-        float* op = yc + ((size_t)od * Ho + oh) * Wo + 2 * w;
-        if (2 * w < Wo) op[0] = r0;
-        if (2 * w + 1 < Wo) op[1] = r1;
+        const size_t o = ((size_t)od * Ho + oh) * Wo + 2 * w;
+        if (yb && 2 * w + 1 < Wo && !((o + (size_t)c * Vo) & 1)) {       // bf16 pair in one aligned 4-byte store (a torch allocation is >= 4-byte aligned)
+          reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(yc) + o)[0] = dpi_pack_bf16(r0, r1);
+        } else {
+          if (2 * w < Wo) dpi_st(yc, o, r0, yb);
+          if (2 * w + 1 < Wo) dpi_st(yc, o + 1, r1, yb);
+        }
       }
     }
   }
@@ -737,11 +745,11 @@ __device__ __forceinline__ void lin_bwd_taps(int i, int n, int no, int (&o)[4], 
 
 template <bool SCALE_D>
 __global__ __launch_bounds__(256) void upsample_lin_bwd_gather_kernel(const float* __restrict__ dy, int D, int H, int W, int Do, int Ho,
-                                                                      int Wo, float* __restrict__ dx) {
+                                                                      int Wo, float* __restrict__ dx, bool gb = false) {
   const int c = blockIdx.y;
   const size_t V = (size_t)D * H * W, Vo = (size_t)Do * Ho * Wo;
-  const float* __restrict__ gc = dy + (size_t)c * Vo;
-  float* __restrict__ oc = dx + (size_t)c * V;
+  const float* __restrict__ gc = dpi_at(dy, (size_t)c * Vo, gb);
+  float* __restrict__ oc = dpi_at(dx, (size_t)c * V, gb);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
     const int w = i % W, h = (i / W) % H, d = i / ((size_t)W * H);
     int ow[4], oh[4], od[4];
@@ -757,13 +765,14 @@ __global__ __launch_bounds__(256) void upsample_lin_bwd_gather_kernel(const floa
       float accd = 0.f;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const float* row = gc + ((size_t)od_ * Ho + oh[b]) * Wo;
-        const float rsum = ww[0] * row[ow[0]] + ww[1] * row[ow[1]] + ww[2] * row[ow[2]] + ww[3] * row[ow[3]];
+        const size_t row = ((size_t)od_ * Ho + oh[b]) * Wo;
+        const float rsum = ww[0] * dpi_ld(gc, row + ow[0], gb) + ww[1] * dpi_ld(gc, row + ow[1], gb) + ww[2] * dpi_ld(gc, row + ow[2], gb)
+                           + ww[3] * dpi_ld(gc, row + ow[3], gb);
         accd = fmaf(wh[b], rsum, accd);
       }
       acc = fmaf(wa, accd, acc);
     }
-    oc[i] = acc;
+    dpi_st(oc, i, acc, gb);
   }
 }
 
@@ -772,7 +781,7 @@ __global__ __launch_bounds__(256) void upsample_lin_bwd_gather_kernel(const floa
 // Three coalesced passes (W, H, D) move 2.6x the gradient once instead of gathering 64 strided values per voxel
 // (8 L1 requests per voxel): 0.95 -> ~0.5 ms for the 51-channel full-resolution tensor.
 __global__ __launch_bounds__(256) void upsample_lin_bwd_axis_kernel(const float* __restrict__ in, float* __restrict__ out, unsigned outer,
-                                                                    int n, int no, unsigned inner) {
+                                                                    int n, int no, unsigned inner, bool ib = false, bool ob = false) {
   // blockIdx.x walks one [n][inner] slab (32-bit index math only), blockIdx.y strides over the outer slabs; a slab shorter
   // than the workgroup (the W pass: one row) shares it with its neighbours
   const unsigned slab = (unsigned)n * inner;
@@ -786,8 +795,8 @@ __global__ __launch_bounds__(256) void upsample_lin_bwd_axis_kernel(const float*
   lin_bwd_taps((int)i, n, no, oo, wt);
   const unsigned o0 = oo[0] * inner + in_i, o1 = oo[1] * inner + in_i, o2 = oo[2] * inner + in_i, o3 = oo[3] * inner + in_i;
   for (unsigned o = blockIdx.y * per + sub; o < outer; o += gridDim.y * per) {
-    const float* __restrict__ p = in + (size_t)o * no * inner;
-    out[(size_t)o * slab + e] = (wt[0] * p[o0] + wt[1] * p[o1]) + (wt[2] * p[o2] + wt[3] * p[o3]);
+    const float* __restrict__ p = dpi_at(in, (size_t)o * no * inner, ib);
+    dpi_st(out, (size_t)o * slab + e, (wt[0] * dpi_ld(p, o0, ib) + wt[1] * dpi_ld(p, o1, ib)) + (wt[2] * dpi_ld(p, o2, ib) + wt[3] * dpi_ld(p, o3, ib)), ob);
   }
 }
 
@@ -849,11 +858,19 @@ extern "C" int dpi_stat_blocks(int C, size_t V) {
   return (int)n;
 }
 
-extern "C" int dpi_channel_stats(const float* x, const float* chain, int C, size_t V, double* partials, void* stream) {
+#define DPI_FB(io) (((io) & DPI_STORE_FWD_BF16) != 0)
+#define DPI_GB(io) (((io) & DPI_STORE_GRAD_BF16) != 0)
+#define DPI_REQUIRE_IO(io, what) DPI_REQUIRE(((io) & ~3u) == 0, what ": unknown storage-type bits in io = %u", (unsigned)(io))
+
+extern "C" int dpi_channel_stats_io(const float* x, const float* chain, int C, size_t V, double* partials, unsigned io, void* stream) {
   DPI_REQUIRE(x && partials && C > 0 && V > 0, "channel_stats: bad argument");
+  DPI_REQUIRE_IO(io, "channel_stats");
   const int nblk = dpi_stat_blocks(C, V);
-  channel_stats_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(x, chain, C, V, nblk, partials);
+  channel_stats_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(x, chain, C, V, nblk, partials, DPI_FB(io));
   return dpi_check_launch("channel_stats");
+}
+extern "C" int dpi_channel_stats(const float* x, const float* chain, int C, size_t V, double* partials, void* stream) {
+  return dpi_channel_stats_io(x, chain, C, V, partials, 0, stream);
 }
 
 extern "C" int dpi_bn_finalize(const double* partials, int nblk, int C, size_t count, const float* gamma, const float* beta,
@@ -867,34 +884,50 @@ extern "C" int dpi_bn_finalize(const double* partials, int nblk, int C, size_t c
   return dpi_check_launch("bn_finalize");
 }
 
-extern "C" int dpi_chain_apply(const float* x, const float* chain, int C, size_t V, float* y, void* stream) {
+extern "C" int dpi_chain_apply_io(const float* x, const float* chain, int C, size_t V, float* y, unsigned io, void* stream) {
   DPI_REQUIRE(x && y && C > 0 && V > 0, "chain_apply: bad argument");
-  chain_apply_kernel<<<dim3(ew_blocks(cdivz(V, 4)), C), 256, 0, (hipStream_t)stream>>>(x, chain, V, y);
+  DPI_REQUIRE_IO(io, "chain_apply");
+  chain_apply_kernel<<<dim3(ew_blocks(cdivz(V, 4)), C), 256, 0, (hipStream_t)stream>>>(x, chain, V, y, DPI_FB(io), DPI_FB(io));
   return dpi_check_launch("chain_apply");
+}
+extern "C" int dpi_chain_apply(const float* x, const float* chain, int C, size_t V, float* y, void* stream) {
+  return dpi_chain_apply_io(x, chain, C, V, y, 0, stream);
 }
 
 extern "C" int dpi_bn_bwd_reduce(const float* dy, const float* x, const float* mean_invstd, const float* gamma, const float* beta,
                                  const float* in_chain, float pre_slope, float post_slope, int C, size_t V, double* partials,
                                  void* stream) {
+  return dpi_bn_bwd_reduce_io(dy, x, mean_invstd, gamma, beta, in_chain, pre_slope, post_slope, C, V, partials, 0, stream);
+}
+extern "C" int dpi_bn_bwd_reduce_io(const float* dy, const float* x, const float* mean_invstd, const float* gamma, const float* beta,
+                                    const float* in_chain, float pre_slope, float post_slope, int C, size_t V, double* partials,
+                                    unsigned io, void* stream) {
   DPI_REQUIRE(dy && x && mean_invstd && partials && C > 0 && V > 0, "bn_bwd_reduce: bad argument");
+  DPI_REQUIRE_IO(io, "bn_bwd_reduce");
   DPI_REQUIRE(!in_chain || pre_slope == 1.f, "bn_bwd_reduce: in_chain excludes pre_slope");
   const int nblk = dpi_stat_blocks(C, V);
   bn_bwd_reduce_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, beta, in_chain, pre_slope, post_slope, C, V,
-                                                                       nblk, partials);
+                                                                       nblk, partials, DPI_FB(io), DPI_GB(io));
   return dpi_check_launch("bn_bwd_reduce");
 }
 
 extern "C" int dpi_bn_bwd_apply(const float* dy, const float* x, const float* mean_invstd, const float* gamma, const float* beta,
                                 const float* in_chain, float pre_slope, float post_slope, const double* partials, int nblk, int C,
                                 size_t V, float* dx, float* dgamma, float* dbeta, void* stream) {
+  return dpi_bn_bwd_apply_io(dy, x, mean_invstd, gamma, beta, in_chain, pre_slope, post_slope, partials, nblk, C, V, dx, dgamma, dbeta, 0, stream);
+}
+extern "C" int dpi_bn_bwd_apply_io(const float* dy, const float* x, const float* mean_invstd, const float* gamma, const float* beta,
+                                   const float* in_chain, float pre_slope, float post_slope, const double* partials, int nblk, int C,
+                                   size_t V, float* dx, float* dgamma, float* dbeta, unsigned io, void* stream) {
   DPI_REQUIRE(dy && x && mean_invstd && partials && dx && C > 0 && V > 0 && nblk > 0, "bn_bwd_apply: bad argument");
+  DPI_REQUIRE_IO(io, "bn_bwd_apply");
   DPI_REQUIRE(!in_chain || pre_slope == 1.f, "bn_bwd_apply: in_chain excludes pre_slope");
   // every workgroup first re-reduces the phase-1 partials of its channel (nblk double pairs): keep >= 8 float4 per thread
   // behind that prologue instead of one
   unsigned gx = ew_blocks(cdivz(V, 4 * 8));
   bn_bwd_apply_kernel<<<dim3(gx, C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, beta, in_chain, pre_slope,
                                                                                       post_slope, partials, nblk, C, V, dx, dgamma,
-                                                                                      dbeta);
+                                                                                      dbeta, DPI_FB(io), DPI_GB(io));
   return dpi_check_launch("bn_bwd_apply");
 }
 
@@ -904,13 +937,24 @@ extern "C" int dpi_bn_bwd_apply_fork(const float* dy, const float* x, const floa
                                      const float* gamma_a, const float* beta_a, const float* chain_a, float post_a, double* partials_a,
                                      const float* xb, const float* mi_b, const float* gamma_b, const float* beta_b, const float* chain_b,
                                      float post_b, double* partials_b, void* stream) {
+  return dpi_bn_bwd_apply_fork_io(dy, x, mean_invstd, gamma, beta, in_chain, pre_slope, post_slope, partials, nblk, C, V, dx, dgamma, dbeta,
+                                  xa, mi_a, gamma_a, beta_a, chain_a, post_a, partials_a, xb, mi_b, gamma_b, beta_b, chain_b, post_b, partials_b, 0,
+                                  stream);
+}
+extern "C" int dpi_bn_bwd_apply_fork_io(const float* dy, const float* x, const float* mean_invstd, const float* gamma, const float* beta,
+                                        const float* in_chain, float pre_slope, float post_slope, const double* partials, int nblk, int C,
+                                        size_t V, float* dx, float* dgamma, float* dbeta, const float* xa, const float* mi_a,
+                                        const float* gamma_a, const float* beta_a, const float* chain_a, float post_a, double* partials_a,
+                                        const float* xb, const float* mi_b, const float* gamma_b, const float* beta_b, const float* chain_b,
+                                        float post_b, double* partials_b, unsigned io, void* stream) {
   DPI_REQUIRE(dy && x && mean_invstd && partials && dx && C > 0 && V > 0 && nblk > 0, "bn_bwd_apply_fork: bad argument");
+  DPI_REQUIRE_IO(io, "bn_bwd_apply_fork");
   DPI_REQUIRE(!in_chain || pre_slope == 1.f, "bn_bwd_apply_fork: in_chain excludes pre_slope");
   DPI_REQUIRE((!xa || (mi_a && partials_a)) && (!xb || (mi_b && partials_b)), "bn_bwd_apply_fork: incomplete follow-up BatchNorm");
   const int nb = dpi_stat_blocks(C, V);
   const BnFork fa{xa, mi_a, gamma_a, beta_a, chain_a, post_a, partials_a}, fb{xb, mi_b, gamma_b, beta_b, chain_b, post_b, partials_b};
   bn_bwd_apply_fork_kernel<<<dim3(nb, C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, beta, in_chain, pre_slope, post_slope,
-                                                                        partials, nblk, C, V, nb, dx, dgamma, dbeta, fa, fb);
+                                                                        partials, nblk, C, V, nb, dx, dgamma, dbeta, fa, fb, DPI_FB(io), DPI_GB(io));
   return dpi_check_launch("bn_bwd_apply_fork");
 }
 
@@ -920,22 +964,38 @@ extern "C" int dpi_bn_bwd_apply_dual(const float* dy, int nblk, int C, size_t V,
                                      const float* beta_b, const float* chain_b, float post_b, const double* partials_b, float* dxb,
                                      float* dgamma_b, float* dbeta_b, int f_lo, int f_hi, const float* f_mi, const float* f_gamma,
                                      const float* f_beta, float f_post, double* f_partials, void* stream) {
+  return dpi_bn_bwd_apply_dual_io(dy, nblk, C, V, xa, mi_a, gamma_a, beta_a, chain_a, post_a, partials_a, dxa, dgamma_a, dbeta_a, xb, mi_b, gamma_b,
+                                  beta_b, chain_b, post_b, partials_b, dxb, dgamma_b, dbeta_b, f_lo, f_hi, f_mi, f_gamma, f_beta, f_post, f_partials, 0,
+                                  stream);
+}
+extern "C" int dpi_bn_bwd_apply_dual_io(const float* dy, int nblk, int C, size_t V, const float* xa, const float* mi_a, const float* gamma_a,
+                                        const float* beta_a, const float* chain_a, float post_a, const double* partials_a, float* dxa,
+                                        float* dgamma_a, float* dbeta_a, const float* xb, const float* mi_b, const float* gamma_b,
+                                        const float* beta_b, const float* chain_b, float post_b, const double* partials_b, float* dxb,
+                                        float* dgamma_b, float* dbeta_b, int f_lo, int f_hi, const float* f_mi, const float* f_gamma,
+                                        const float* f_beta, float f_post, double* f_partials, unsigned io, void* stream) {
   DPI_REQUIRE(dy && xa && xb && mi_a && mi_b && partials_a && partials_b && dxa && dxb && C > 0 && V > 0 && nblk > 0,
               "bn_bwd_apply_dual: bad argument");
+  DPI_REQUIRE_IO(io, "bn_bwd_apply_dual");
   DPI_REQUIRE(!f_partials || (f_mi && f_lo >= 0 && f_hi <= C && f_lo < f_hi), "bn_bwd_apply_dual: bad fork range");
   const int nb = dpi_stat_blocks(C, V);
   const BnSide A{xa, mi_a, gamma_a, beta_a, chain_a, post_a, partials_a, dxa, dgamma_a, dbeta_a};
   const BnSide B{xb, mi_b, gamma_b, beta_b, chain_b, post_b, partials_b, dxb, dgamma_b, dbeta_b};
   bn_bwd_apply_dual_kernel<<<dim3(nb, C), 256, 0, (hipStream_t)stream>>>(dy, A, B, nblk, C, V, nb, f_lo, f_hi, f_mi, f_gamma, f_beta, f_post,
-                                                                        f_partials);
+                                                                        f_partials, DPI_FB(io), DPI_GB(io));
   return dpi_check_launch("bn_bwd_apply_dual");
 }
 
 extern "C" int dpi_chain_add_stats(const float* a, const float* chain_a, const float* b, const float* chain_b, int C, size_t V,
                                    float slope, float* t, double* partials, void* stream) {
+  return dpi_chain_add_stats_io(a, chain_a, b, chain_b, C, V, slope, t, partials, 0, stream);
+}
+extern "C" int dpi_chain_add_stats_io(const float* a, const float* chain_a, const float* b, const float* chain_b, int C, size_t V,
+                                      float slope, float* t, double* partials, unsigned io, void* stream) {
   DPI_REQUIRE(a && b && t && partials && C > 0 && V > 0, "chain_add_stats: bad argument");
+  DPI_REQUIRE_IO(io, "chain_add_stats");
   const int nblk = dpi_stat_blocks(C, V);
-  chain_add_stats_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(a, chain_a, b, chain_b, C, V, nblk, slope, t, partials);
+  chain_add_stats_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(a, chain_a, b, chain_b, C, V, nblk, slope, t, partials, DPI_FB(io));
   return dpi_check_launch("chain_add_stats");
 }
 
@@ -974,17 +1034,23 @@ extern "C" int dpi_channel_sum(const float* x, int C, size_t V, double* ws, floa
 
 extern "C" int dpi_upsample2x_fwd(const float* x, const float* chain, int C, int D, int H, int W, int Do, int Ho, int Wo,
                                   int linear, float* y, void* stream) {
+  return dpi_upsample2x_fwd_io(x, chain, C, D, H, W, Do, Ho, Wo, linear, y, 0, stream);
+}
+extern "C" int dpi_upsample2x_fwd_io(const float* x, const float* chain, int C, int D, int H, int W, int Do, int Ho, int Wo,
+                                     int linear, float* y, unsigned io, void* stream) {
   DPI_REQUIRE(x && y && C > 0 && D > 0 && H > 0 && W > 0, "upsample_fwd: bad argument");
+  DPI_REQUIRE_IO(io, "upsample_fwd");
+  const bool fb = DPI_FB(io);
   const int scale_d = !(D == 1 && Do == 1);
   DPI_REQUIRE(Do >= 1 && Ho >= 1 && Wo >= 1 && Do <= (scale_d ? 2 * D : 1) && Ho <= 2 * H && Wo <= 2 * W,
               "upsample_fwd: output (%d,%d,%d) exceeds 2x input (%d,%d,%d)", Do, Ho, Wo, D, H, W);
   const size_t Vo = (size_t)Do * Ho * Wo, V = (size_t)D * H * W;
   if (linear && H > 1 && W > 1 && (!scale_d || D > 1)) {
-    if (scale_d) upsample_lin_fwd_cube_kernel<true><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, y);
-    else upsample_lin_fwd_cube_kernel<false><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, y);
+    if (scale_d) upsample_lin_fwd_cube_kernel<true><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, y, fb, fb);
+    else upsample_lin_fwd_cube_kernel<false><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, y, fb, fb);
     return dpi_check_launch("upsample_lin_fwd_cube");
   }
-  upsample_fwd_kernel<<<dim3(ew_blocks(Vo), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, linear, scale_d, y);
+  upsample_fwd_kernel<<<dim3(ew_blocks(Vo), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, linear, scale_d, y, fb, fb);
   return dpi_check_launch("upsample_fwd");
 }
 
@@ -996,7 +1062,13 @@ extern "C" size_t dpi_upsample2x_bwd_ws_floats(int C, int D, int H, int W, int D
 
 extern "C" int dpi_upsample2x_bwd(const float* dy, int C, int D, int H, int W, int Do, int Ho, int Wo, int linear, float* dx,
                                   float* ws, void* stream) {
+  return dpi_upsample2x_bwd_io(dy, C, D, H, W, Do, Ho, Wo, linear, dx, ws, 0, stream);
+}
+extern "C" int dpi_upsample2x_bwd_io(const float* dy, int C, int D, int H, int W, int Do, int Ho, int Wo, int linear, float* dx,
+                                     float* ws, unsigned io, void* stream) {
   DPI_REQUIRE(dy && dx && C > 0 && D > 0 && H > 0 && W > 0, "upsample_bwd: bad argument");
+  DPI_REQUIRE_IO(io, "upsample_bwd");
+  const bool gb = DPI_GB(io);        // dy and dx; the workspace of the separable passes stays fp32
   const int scale_d = !(D == 1 && Do == 1);
   const size_t V = (size_t)D * H * W;
   if (linear && ws) {                                   // separable passes through the caller's workspace
@@ -1006,24 +1078,24 @@ extern "C" int dpi_upsample2x_bwd(const float* dy, int C, int D, int H, int W, i
     // the axis kernel indexes one [n][inner] (output) / [no][inner] (input) slab and the slab count with 32 bits
     DPI_REQUIRE((size_t)C * Do * Ho < (1ull << 32) && (size_t)Do * Ho * Wo < (1ull << 31) && (size_t)Do * H * W < (1ull << 31),
                 "upsample_bwd: %d x %d x %d x %d exceeds the 32-bit slab indexing of the separable adjoint", C, Do, Ho, Wo);
-    auto launch = [&](const float* src, float* dst, size_t outer, int n, int no, size_t inner) {
+    auto launch = [&](const float* src, float* dst, size_t outer, int n, int no, size_t inner, bool ib, bool ob) {
       const unsigned gx = (unsigned)cdivz((size_t)n * inner, 256);
       // enough slabs per launch to fill the chip, each workgroup then strides over the rest
       size_t gy = outer < 65535 ? outer : 65535;
       while (gy > 1 && (size_t)gx * gy > 16384) gy = (gy + 1) / 2;
-      upsample_lin_bwd_axis_kernel<<<dim3(gx, (unsigned)gy), 256, 0, st>>>(src, dst, (unsigned)outer, n, no, (unsigned)inner);
+      upsample_lin_bwd_axis_kernel<<<dim3(gx, (unsigned)gy), 256, 0, st>>>(src, dst, (unsigned)outer, n, no, (unsigned)inner, ib, ob);
     };
-    launch(dy, t1, (size_t)C * Do * Ho, W, Wo, 1);
-    launch(t1, scale_d ? t2 : dx, (size_t)C * Do, H, Ho, W);
-    if (scale_d) launch(t2, dx, C, D, Do, (size_t)H * W);
+    launch(dy, t1, (size_t)C * Do * Ho, W, Wo, 1, gb, false);
+    launch(t1, scale_d ? t2 : dx, (size_t)C * Do, H, Ho, W, false, scale_d ? false : gb);
+    if (scale_d) launch(t2, dx, C, D, Do, (size_t)H * W, false, gb);
     return dpi_check_launch("upsample_lin_bwd_axis");
   }
   if (linear) {
-    if (scale_d) upsample_lin_bwd_gather_kernel<true><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, dx);
-    else upsample_lin_bwd_gather_kernel<false><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, dx);
+    if (scale_d) upsample_lin_bwd_gather_kernel<true><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, dx, gb);
+    else upsample_lin_bwd_gather_kernel<false><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, dx, gb);
     return dpi_check_launch("upsample_lin_bwd_gather");
   }
-  upsample_bwd_kernel<<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, linear, scale_d, dx);
+  upsample_bwd_kernel<<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, linear, scale_d, dx, gb);
   return dpi_check_launch("upsample_bwd");
 }
 

@@ -108,7 +108,7 @@ __device__ __forceinline__ void philox4(uint64_t ctr, uint64_t stream_id, uint64
 
 __global__ __launch_bounds__(256) void noise_kernel(const float* __restrict__ zin, size_t n, float mean, float std, uint64_t seed,
                                                     const uint64_t* __restrict__ step_ptr, uint64_t stream_id,
-                                                    float* __restrict__ out) {
+                                                    float* __restrict__ out, bool ob = false) {        // ob: `out` is stored as bf16
   typedef float nz_f32x4 __attribute__((ext_vector_type(4)));
   const uint64_t sid = step_ptr ? *step_ptr : stream_id;
   const bool vec = (n & 3) == 0;
@@ -124,10 +124,9 @@ __global__ __launch_bounds__(256) void noise_kernel(const float* __restrict__ zi
         else b = *reinterpret_cast<const float4*>(zin + i);
       }
       b.x = fmaf(std, z[0], b.x); b.y = fmaf(std, z[1], b.y); b.z = fmaf(std, z[2], b.z); b.w = fmaf(std, z[3], b.w);
-      if (nt) __builtin_nontemporal_store((nz_f32x4){b.x, b.y, b.z, b.w}, reinterpret_cast<nz_f32x4*>(out + i));
-      else *reinterpret_cast<float4*>(out + i) = b;
+      dpi_st4(out, i, b, ob, nt);
     } else {
-      for (int k = 0; k < 4 && i + k < n; ++k) out[i + k] = fmaf(std, z[k], zin ? zin[i + k] : mean);
+      for (int k = 0; k < 4 && i + k < n; ++k) dpi_st(out, i + k, fmaf(std, z[k], zin ? zin[i + k] : mean), ob);
     }
   }
 }
@@ -233,11 +232,16 @@ extern "C" int dpi_adam_multi(const dpi_adam_tensor* tensors, const int64_t* siz
   return dpi_check_launch("adam_multi");
 }
 
+extern "C" int dpi_noise_add_io(const float* z, size_t n, float std, uint64_t seed, const uint64_t* step_ptr, float* out, unsigned io,
+                                void* stream) {
+  DPI_REQUIRE(z && out && n > 0, "noise_add: bad argument");
+  DPI_REQUIRE((io & ~3u) == 0, "noise_add: unknown storage-type bits in io = %u", io);
+  noise_kernel<<<nblocks(cdivz(n, 4)), 256, 0, (hipStream_t)stream>>>(z, n, 0.f, std, seed, step_ptr, 0, out, (io & DPI_STORE_FWD_BF16) != 0);
+  return dpi_check_launch("noise_add");
+}
 extern "C" int dpi_noise_add(const float* z, size_t n, float std, uint64_t seed, const uint64_t* step_ptr, float* out,
                              void* stream) {
-  DPI_REQUIRE(z && out && n > 0, "noise_add: bad argument");
-  noise_kernel<<<nblocks(cdivz(n, 4)), 256, 0, (hipStream_t)stream>>>(z, n, 0.f, std, seed, step_ptr, 0, out);
-  return dpi_check_launch("noise_add");
+  return dpi_noise_add_io(z, n, std, seed, step_ptr, out, 0, stream);
 }
 
 extern "C" int dpi_fill_normal(float* out, size_t n, float mean, float std, uint64_t seed, uint64_t stream_id, void* stream) {

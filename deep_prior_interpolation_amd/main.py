@@ -90,6 +90,7 @@ class Interpolator:
             self.net = get_net(self.args, self.outchannel)
             u.init_weights(self.net, self.args.inittype, self.args.initgain)
         self.net = self.net.float().to(self.device)
+        self._storage_ok = None
         self.num_params = sum(int(np.prod(list(p.size()))) for p in self.net.parameters())
 
     def build_input(self):
@@ -124,11 +125,14 @@ class Interpolator:
         """input = z + reg_noise_std * N(0,1), fresh every iteration (main.py:148-150)."""
         if self.args.reg_noise_std <= 0:
             return self.input_
-        out = torch.empty_like(self.input_)
+        # (bf16 storage: the perturbed input is the first activation the net reads — 64 channels at full resolution — and is written as
+        #  bf16 straight away; z itself stays fp32)
+        bf = ops.STORAGE_BF16 and self.input_.ndim == 5
+        out = torch.empty_like(self.input_, dtype=torch.bfloat16) if bf else torch.empty_like(self.input_)
         self._noise_step += 1
-        _lib.check(_lib.load().dpi_noise_add(_lib.ptr(self.input_), out.numel(), float(self.args.reg_noise_std),
-                                             self.noise_seed, _lib.ptr(self._noise_step), _lib.ptr(out), _lib.stream()),
-                   "dpi_noise_add")
+        _lib.check(_lib.load().dpi_noise_add_io(_lib.ptr(self.input_), out.numel(), float(self.args.reg_noise_std),
+                                                self.noise_seed, _lib.ptr(self._noise_step), _lib.ptr(out),
+                                                _lib.STORE_FWD_BF16 if bf else 0, _lib.stream()), "dpi_noise_add")
         return out
 
     def _to_numpy_out(self, out_):
@@ -143,6 +147,26 @@ class Interpolator:
         prec = getattr(self.args, "precision", "fp32")
         if prec != "fp32" or "DPI_PRECISION" not in os.environ:
             ops.set_precision(prec)
+        # bf16 STORAGE of the activations (BASELINE configs[4]) where every node of the net is a fused 3-D node that takes it
+        ops.set_storage("bf16" if (prec == "bf16" and self.storage_bf16_ok()) else "fp32")
+
+    def storage_bf16_ok(self):
+        """Whether this net runs with bf16 activations: the 3-D MultiRes-UNet whose blocks all execute as the fused nodes
+        (LeakyReLU, no dropout) — Block3dFn / SkipJoinFn / ConvBnActFn allocate the tensors and every kernel under them takes the
+        storage type.  Other nets keep fp32 storage under --precision bf16 (operand rounding only, as --precision bf16mm)."""
+        ok = getattr(self, "_storage_ok", None)
+        if ok is None:
+            from .architectures import mulresunet as M
+            a = self.args
+            # (the data-forgetting term adds the fp32 data to the network input on the host side of the node boundary: fp32 storage)
+            ok = bool(self.net is not None and a.datadim == "3d" and getattr(a, "net", "multiunet") in ("multiunet", "load") and M.FUSE_BLOCKS
+                      and a.data_forgetting_factor == 0)
+            if ok:
+                blocks = [m for m in self.net.modules() if isinstance(m, (M.MultiResBlock, M.ResPath))]
+                ok = bool(blocks) and all(m.nd == 3 and m._fusable() for m in blocks)
+            if self.net is not None:
+                self._storage_ok = ok
+        return ok
 
     def optimization_loop(self, net_input=None):
         self.apply_precision()

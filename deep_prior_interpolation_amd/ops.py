@@ -16,12 +16,46 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
-def _req(t, name):
+def _req(t, name, act=False):
+    """act=True: an ACTIVATION (or the gradient of one) of a fused 3-D node — float32, or bfloat16 in the bf16-storage mode."""
     if not t.is_cuda:
         raise _lib.DpiError("%s must live on the GPU: the HIP path has no CPU fallback" % name)
-    if t.dtype != torch.float32:
-        raise _lib.DpiError("%s must be float32 (got %s)" % (name, t.dtype))
+    if t.dtype != torch.float32 and not (act and t.dtype == torch.bfloat16):
+        raise _lib.DpiError("%s must be float32%s (got %s)" % (name, " or bfloat16" if act else "", t.dtype))
     return t.contiguous()
+
+
+# ---- storage type of activations in HBM (BASELINE configs[4]: "bf16 activations + fp32 Adam master weights") ---------------------------
+# False: every tensor fp32 (the reference's storage, main.py:112).  True: the fused 3-D nodes (Block3dFn, ResPath3dFn, SkipJoinFn,
+# ConvBnActFn) allocate their forward tensors (R, S, t, y, cat) AND the gradients of those as torch.bfloat16; the kernels widen on load and
+# round to nearest-even on store (dpi_conv_desc.io, the *_io entry points), arithmetic / BatchNorm statistics / weights / weight gradients /
+# Adam stay fp32.  A leaf convolution (the network's output layer) reads bf16 and writes fp32, so loss and metrics see fp32.
+STORAGE_BF16 = os.environ.get("DPI_STORAGE", "fp32") == "bf16"
+
+
+def set_storage(name):
+    global STORAGE_BF16
+    if name not in ("fp32", "bf16"):
+        raise ValueError("storage must be fp32 or bf16")
+    STORAGE_BF16 = name == "bf16"
+
+
+def act_dtype():
+    return torch.bfloat16 if STORAGE_BF16 else torch.float32
+
+
+def _bf(t):
+    return t is not None and t.dtype == torch.bfloat16
+
+
+def _io(fwd=None, grad=None):
+    """`io` mask of an *_io entry point from the tensors themselves."""
+    return (_lib.STORE_FWD_BF16 if _bf(fwd) else 0) | (_lib.STORE_GRAD_BF16 if _bf(grad) else 0)
+
+
+def _same_type(a, b, what):
+    if a.dtype != b.dtype:
+        raise _lib.DpiError("%s: tensors of one call must share their storage type (got %s and %s)" % (what, a.dtype, b.dtype))
 
 
 def _dims(x):
@@ -47,7 +81,9 @@ def conv_out(n, k, s):
 # operands to the matrix cores with fp32 accumulation; tensors, master weights, BatchNorm statistics and Adam stay fp32.
 # 2: "split" mode — fp32 operands split exactly into three bf16 terms, six partial products accumulated in fp32: fp32-class accuracy
 # on the bf16 matrix cores (forward / backward-data of the shapes where the kernel wins).
-_PRECISIONS = {"fp32": 0, "bf16": 1, "split": 2}
+# "bf16mm" is mode 1 under its round-2/3 meaning (operands only); "bf16" is the same arithmetic and, where the net supports it, bf16
+# STORAGE of the activations on top (Interpolator.apply_precision -> set_storage; round 4).
+_PRECISIONS = {"fp32": 0, "bf16": 1, "bf16mm": 1, "split": 2}
 PRECISION = _PRECISIONS.get(os.environ.get("DPI_PRECISION", "fp32"), 0)
 
 
@@ -58,13 +94,16 @@ def set_precision(name):
     PRECISION = _PRECISIONS[name]
 
 
-def make_desc(x, w, stride):
+def make_desc(x, w, stride, ydt=torch.float32):
+    """Descriptor of one layer.  `ydt`: storage type of the layer's OUTPUT; the gradient of a tensor shares the tensor's type
+    (autograd's rule), so x decides the X and DX bits and ydt the Y and DY bits of dpi_conv_desc.io."""
     Cin, D, H, W = _dims(x)
     k = w.shape[-1]
     kd = w.shape[2] if w.ndim == 5 else 1
     if w.shape[1] != Cin:
         raise _lib.DpiError("conv: weight expects %d input channels, tensor has %d" % (w.shape[1], Cin))
-    return ConvDesc(Cin, w.shape[0], D, H, W, k, kd, int(stride), PRECISION)
+    io = ((_lib.IO_X_BF16 | _lib.IO_DX_BF16) if _bf(x) else 0) | ((_lib.IO_Y_BF16 | _lib.IO_DY_BF16) if ydt == torch.bfloat16 else 0)
+    return ConvDesc(Cin, w.shape[0], D, H, W, k, kd, int(stride), PRECISION, io)
 
 
 def desc_out_dims(d):
@@ -153,7 +192,7 @@ def _ws_floats(kind, d):
     round trips per eager iteration otherwise.  Forward / backward-data only, where a stale answer is harmless: the
     library ignores a workspace it does not need and runs the unsplit launch when it gets none (include/dpi_hip.h); the split /
     kernel-selection knobs (dpi_set_splitk, dpi_set_q4, ...) are test / tool hooks — `reset_ws_cache()` after flipping one."""
-    key = (kind, d.Cin, d.Cout, d.D, d.H, d.W, d.k, d.kd, d.stride, d.precision, getattr(d, "io", 0))
+    key = (kind, d.Cin, d.Cout, d.D, d.H, d.W, d.k, d.kd, d.stride, d.precision, d.io)
     n = _ws_cache.get(key)
     if n is None:
         L = _lib.load()
@@ -290,7 +329,7 @@ def raw_bn_stats_finalize(x, chain_in, C_, V, gamma, beta, slope, running_mean, 
     L = _lib.load()
     nblk = L.dpi_stat_blocks(C_, V)
     part = torch.empty(nblk * C_ * 2, dtype=torch.float64, device=x.device)
-    check(L.dpi_channel_stats(ptr(x), ptr(chain_in), C_, V, ptr(part), stream()), "dpi_channel_stats")
+    check(L.dpi_channel_stats_io(ptr(x), ptr(chain_in), C_, V, ptr(part), _io(x), stream()), "dpi_channel_stats")
     check(L.dpi_bn_finalize(ptr(part), nblk, C_, V, ptr(gamma), ptr(beta), eps, momentum, slope, act_first,
                             ptr(chain_in) if compose else None, ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean_invstd),
                             ptr(chain_out), stream()), "dpi_bn_finalize")
@@ -308,12 +347,14 @@ def raw_upsample2x_bwd(dy, C_, D, H, W, Do, Ho, Wo, linear, dx):
     L = _lib.load()
     n = L.dpi_upsample2x_bwd_ws_floats(C_, D, H, W, Do, Ho, Wo, linear)
     ws = torch.empty(n, dtype=torch.float32, device=dy.device) if n else None
-    check(L.dpi_upsample2x_bwd(ptr(dy), C_, D, H, W, Do, Ho, Wo, linear, ptr(dx), ptr(ws), stream()), "dpi_upsample2x_bwd")
+    _same_type(dy, dx, "upsample2x_bwd")
+    check(L.dpi_upsample2x_bwd_io(ptr(dy), C_, D, H, W, Do, Ho, Wo, linear, ptr(dx), ptr(ws), _io(None, dy), stream()), "dpi_upsample2x_bwd")
 
 
 def raw_chain_apply(x, chain, C_, V, y):
     L = _lib.load()
-    check(L.dpi_chain_apply(ptr(x), ptr(chain), C_, V, ptr(y), stream()), "dpi_chain_apply")
+    _same_type(x, y, "chain_apply")
+    check(L.dpi_chain_apply_io(ptr(x), ptr(chain), C_, V, ptr(y), _io(x), stream()), "dpi_chain_apply")
 
 
 _slope_chains = {}
@@ -337,7 +378,9 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, stride):
-        x, w = _req(x, "conv input"), _req(w, "conv weight")
+        # (a bf16 input — the last fused block's output in the bf16-storage mode — is read as it is; the output of a leaf convolution is
+        #  always fp32: it is the network's output layer, and the loss / metrics kernels take fp32)
+        x, w = _req(x, "conv input", act=True), _req(w, "conv weight")
         b = _req(b, "conv bias") if b is not None else None
         d = make_desc(x, w, stride)
         Do, Ho, Wo = desc_out_dims(d)
@@ -375,14 +418,16 @@ def _bn_backward(dy, x, mi, gamma, beta, pre_slope, post_slope, in_chain=None, d
     V = x.numel() // C_
     nblk = L.dpi_stat_blocks(C_, V)
     part = torch.empty(nblk * C_ * 2, dtype=torch.float64, device=x.device)
-    check(L.dpi_bn_bwd_reduce(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), ptr(in_chain), pre_slope, post_slope, C_, V,
-                              ptr(part), stream()), "dpi_bn_bwd_reduce")
+    io = _io(x, dy)
+    check(L.dpi_bn_bwd_reduce_io(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), ptr(in_chain), pre_slope, post_slope, C_, V,
+                                 ptr(part), io, stream()), "dpi_bn_bwd_reduce")
     if dx is None:
-        dx = torch.empty_like(x)
+        dx = torch.empty_like(dy)
+    _same_type(dy, dx, "bn_backward")
     dgamma = torch.empty_like(gamma)
     dbeta = torch.empty_like(gamma)
-    check(L.dpi_bn_bwd_apply(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), ptr(in_chain), pre_slope, post_slope, ptr(part), nblk,
-                             C_, V, ptr(dx), ptr(dgamma), ptr(dbeta), stream()), "dpi_bn_bwd_apply")
+    check(L.dpi_bn_bwd_apply_io(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), ptr(in_chain), pre_slope, post_slope, ptr(part), nblk,
+                                C_, V, ptr(dx), ptr(dgamma), ptr(dbeta), io, stream()), "dpi_bn_bwd_apply")
     return dx, dgamma, dbeta
 
 
@@ -395,20 +440,22 @@ def _bn_backward_fork(dy, x, mi, gamma, beta, pre_slope, post_slope, forks):
     V = x.numel() // C_
     nblk = L.dpi_stat_blocks(C_, V)
     part = torch.empty(nblk * C_ * 2, dtype=torch.float64, device=x.device)
-    check(L.dpi_bn_bwd_reduce(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), None, pre_slope, post_slope, C_, V, ptr(part),
-                              stream()), "dpi_bn_bwd_reduce")
-    dx = torch.empty_like(x)
+    io = _io(x, dy)
+    check(L.dpi_bn_bwd_reduce_io(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), None, pre_slope, post_slope, C_, V, ptr(part),
+                                 io, stream()), "dpi_bn_bwd_reduce")
+    dx = torch.empty_like(dy)
     dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
     fparts = [torch.empty(nblk * C_ * 2, dtype=torch.float64, device=x.device) for _ in forks]
     fa = []
     for k in range(2):
         if k < len(forks):
             xk, mik, gk, ek, chk, postk = forks[k]
+            _same_type(x, xk, "bn_backward_fork")
             fa += [ptr(xk), ptr(mik), ptr(gk), ptr(ek), ptr(chk), postk, ptr(fparts[k])]
         else:
             fa += [None, None, None, None, None, 1.0, None]
-    check(L.dpi_bn_bwd_apply_fork(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), None, pre_slope, post_slope, ptr(part), nblk, C_, V,
-                                  ptr(dx), ptr(dgamma), ptr(dbeta), *fa, stream()), "dpi_bn_bwd_apply_fork")
+    check(L.dpi_bn_bwd_apply_fork_io(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), None, pre_slope, post_slope, ptr(part), nblk, C_, V,
+                                     ptr(dx), ptr(dgamma), ptr(dbeta), *fa, io, stream()), "dpi_bn_bwd_apply_fork")
     return dx, dgamma, dbeta, [(nblk, fp) for fp in fparts]
 
 
@@ -419,10 +466,11 @@ def _bn_backward_apply(dy, x, mi, gamma, beta, pre_slope, post_slope, red, in_ch
     V = x.numel() // C_
     nblk, part = red
     if dx is None:
-        dx = torch.empty_like(x)
+        dx = torch.empty_like(dy)
+    _same_type(dy, dx, "bn_backward_apply")
     dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
-    check(L.dpi_bn_bwd_apply(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), ptr(in_chain), pre_slope, post_slope, ptr(part), nblk,
-                             C_, V, ptr(dx), ptr(dgamma), ptr(dbeta), stream()), "dpi_bn_bwd_apply")
+    check(L.dpi_bn_bwd_apply_io(ptr(dy), ptr(x), ptr(mi), ptr(gamma), ptr(beta), ptr(in_chain), pre_slope, post_slope, ptr(part), nblk,
+                                C_, V, ptr(dx), ptr(dgamma), ptr(dbeta), _io(x, dy), stream()), "dpi_bn_bwd_apply")
     return dx, dgamma, dbeta
 
 
@@ -437,7 +485,8 @@ def _bn_backward_apply_dual(dy, side_a, side_b, fork=None):
     assert nblk == nblk_b
     C_ = xa.shape[1]
     V = xa.numel() // C_
-    dxa, dxb = torch.empty_like(xa), torch.empty_like(xb)
+    _same_type(xa, xb, "bn_backward_apply_dual")
+    dxa, dxb = torch.empty_like(dy), torch.empty_like(dy)
     dga, dea, dgb, deb = (torch.empty_like(g) for g in (ga, ga, gb, gb))
     red_f = None
     fargs = [0, 0, None, None, None, 1.0, None]
@@ -447,10 +496,10 @@ def _bn_backward_apply_dual(dy, side_a, side_b, fork=None):
         pf = torch.empty(nb * (hi - lo) * 2, dtype=torch.float64, device=xa.device)
         fargs = [lo, hi, ptr(mif), ptr(gf), ptr(ef), postf, ptr(pf)]
         red_f = (nb, pf)
-    check(L.dpi_bn_bwd_apply_dual(ptr(dy), nblk, C_, V,
-                                  ptr(xa), ptr(mia), ptr(ga), ptr(ea), ptr(cha), posta, ptr(parta), ptr(dxa), ptr(dga), ptr(dea),
-                                  ptr(xb), ptr(mib), ptr(gb), ptr(eb), ptr(chb), postb, ptr(partb), ptr(dxb), ptr(dgb), ptr(deb),
-                                  *fargs, stream()), "dpi_bn_bwd_apply_dual")
+    check(L.dpi_bn_bwd_apply_dual_io(ptr(dy), nblk, C_, V,
+                                     ptr(xa), ptr(mia), ptr(ga), ptr(ea), ptr(cha), posta, ptr(parta), ptr(dxa), ptr(dga), ptr(dea),
+                                     ptr(xb), ptr(mib), ptr(gb), ptr(eb), ptr(chb), postb, ptr(partb), ptr(dxb), ptr(dgb), ptr(deb),
+                                     *fargs, _io(xa, dy), stream()), "dpi_bn_bwd_apply_dual")
     return (dxa, dga, dea), (dxb, dgb, deb), red_f
 
 
@@ -497,11 +546,14 @@ class ConvBnActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, stride, slope):
-        x, w = _req(x, "conv input"), _req(w, "conv weight")
-        d = make_desc(x, w, stride)
+        x, w = _req(x, "conv input", act=True), _req(w, "conv weight")
+        adt = act_dtype() if x.ndim == 5 else torch.float32
+        if x.ndim != 5 and _bf(x):
+            raise _lib.DpiError("conv_bn_act: bf16 storage is built for the 3-D nets only")
+        d = make_desc(x, w, stride, adt)
         Do, Ho, Wo = desc_out_dims(d)
         L = _lib.load()
-        r = torch.empty(_like_spatial(x, d.Cout, Do, Ho, Wo), dtype=torch.float32, device=x.device)
+        r = torch.empty(_like_spatial(x, d.Cout, Do, Ho, Wo), dtype=adt, device=x.device)
         nblk = L.dpi_conv_fwd_stat_blocks(C.byref(d))
         part = torch.empty(nblk * d.Cout * 2, dtype=torch.float64, device=x.device)
         raw_conv_fwd(d, x, None, w, b, r, part)
@@ -519,7 +571,7 @@ class ConvBnActFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, r, gamma, beta, mi = ctx.saved_tensors
         d = ctx.d
-        dr, dgamma, dbeta = _bn_backward(_req(dy, "conv-bn-act grad"), r, mi, gamma, beta, 1.0, ctx.slope)
+        dr, dgamma, dbeta = _bn_backward(_req(dy, "conv-bn-act grad", act=True), r, mi, gamma, beta, 1.0, ctx.slope)
         dx = dw = db = None
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
@@ -563,34 +615,35 @@ class Block3dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, blk, slope, *p):
-        x = _req(x, "block input")
+        x = _req(x, "block input", act=True)
         (w1, b1, g1, e1, w2, b2, g2, e2, w3, b3, g3, e3, ws, bs, gs, es, gA, eA, gB, eB) = p
         L = _lib.load()
         dev = x.device
         f32 = dict(dtype=torch.float32, device=dev)
+        adt = act_dtype()                                    # storage type of R, S, t, y (and of their gradients in the backward)
         c1, c2, c3 = w1.shape[0], w2.shape[0], w3.shape[0]
         Ct = c1 + c2 + c3
         bn1_, bn2_, bn3_, bns_ = (m._parts()[1] for m in (blk.conv3x3, blk.conv5x5, blk.conv7x7, blk.shortcut))
-        d1 = make_desc(x, w1, 1)
+        d1 = make_desc(x, w1, 1, adt)
         Do, Ho, Wo = desc_out_dims(d1)
         V = Do * Ho * Wo
-        R = torch.empty(_like_spatial(x, Ct, Do, Ho, Wo), **f32)
+        R = torch.empty(_like_spatial(x, Ct, Do, Ho, Wo), dtype=adt, device=dev)
         CH = torch.empty(Ct * 5, **f32)
         r1, r2, r3 = R[:, :c1], R[:, c1:c1 + c2], R[:, c1 + c2:]
         ch1, ch2, ch3 = CH[:c1 * 5], CH[c1 * 5:(c1 + c2) * 5], CH[(c1 + c2) * 5:]
         mi1, mi2, mi3 = (torch.empty(2 * c, **f32) for c in (c1, c2, c3))
         miA, miS, miB = (torch.empty(2 * Ct, **f32) for _ in range(3))
         _cba_raw(d1, x, None, w1, b1, bn1_, slope, r1, mi1, ch1)
-        d2 = make_desc(r1, w2, 1)
+        d2 = make_desc(r1, w2, 1, adt)
         _cba_raw(d2, r1, ch1, w2, b2, bn2_, slope, r2, mi2, ch2)
-        d3 = make_desc(r2, w3, 1)
+        d3 = make_desc(r2, w3, 1, adt)
         _cba_raw(d3, r2, ch2, w3, b3, bn3_, slope, r3, mi3, ch3)
         # bn1 over the virtual concat T_CH(R); chA = bn1 o T_CH
         chA = torch.empty(Ct * 5, **f32)
         A = blk.bn1
         raw_bn_stats_finalize(R, CH, Ct, V, gA, eA, 1.0, A.running_mean, A.running_var, A.num_batches_tracked, miA, chA,
                               compose=True)
-        dsc = make_desc(x, ws, 1)
+        dsc = make_desc(x, ws, 1, adt)
         S = torch.empty_like(R)
         chS = torch.empty(Ct * 5, **f32)
         _cba_raw(dsc, x, None, ws, bs, bns_, slope, S, miS, chS)
@@ -598,7 +651,7 @@ class Block3dFn(torch.autograd.Function):
         t = torch.empty_like(R)
         nblk = L.dpi_stat_blocks(Ct, V)
         part = torch.empty(nblk * Ct * 2, dtype=torch.float64, device=dev)
-        check(L.dpi_chain_add_stats(ptr(S), ptr(chS), ptr(R), ptr(chA), Ct, V, slope, ptr(t), ptr(part), stream()),
+        check(L.dpi_chain_add_stats_io(ptr(S), ptr(chS), ptr(R), ptr(chA), Ct, V, slope, ptr(t), ptr(part), _io(R), stream()),
               "dpi_chain_add_stats")
         chB = torch.empty(Ct * 5, **f32)
         B = blk.bn2
@@ -615,7 +668,7 @@ class Block3dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        dy = _req(dy, "block grad")
+        dy = _req(dy, "block grad", act=True)
         x, R, S, t, CH, mi1, mi2, mi3, miA, miS, miB = ctx.saved_tensors[:11]
         it = iter(ctx.saved_tensors[11:])
         p = [None if isnone else next(it) for isnone in ctx.none_mask]
@@ -662,16 +715,17 @@ class ResPath3dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, rp, slope, *p):
-        x = _req(x, "respath input")
+        x = _req(x, "respath input", act=True)
         (w3, b3, g3, e3, w1, b1, g1, e1, gB, eB) = p
         L = _lib.load()
         f32 = dict(dtype=torch.float32, device=x.device)
+        adt = act_dtype()
         Ct = w3.shape[0]
         bn3_, bn1_ = rp.conv3x3._parts()[1], rp.conv1x1._parts()[1]
-        d3, d1 = make_desc(x, w3, 1), make_desc(x, w1, 1)
+        d3, d1 = make_desc(x, w3, 1, adt), make_desc(x, w1, 1, adt)
         Do, Ho, Wo = desc_out_dims(d3)
         V = Do * Ho * Wo
-        r3 = torch.empty(_like_spatial(x, Ct, Do, Ho, Wo), **f32)
+        r3 = torch.empty(_like_spatial(x, Ct, Do, Ho, Wo), dtype=adt, device=x.device)
         r1 = torch.empty_like(r3)
         mi3, mi1, miB = (torch.empty(2 * Ct, **f32) for _ in range(3))
         ch3, ch1, chB = (torch.empty(5 * Ct, **f32) for _ in range(3))
@@ -680,7 +734,7 @@ class ResPath3dFn(torch.autograd.Function):
         t = torch.empty_like(r3)
         nblk = L.dpi_stat_blocks(Ct, V)
         part = torch.empty(nblk * Ct * 2, dtype=torch.float64, device=x.device)
-        check(L.dpi_chain_add_stats(ptr(r1), ptr(ch1), ptr(r3), ptr(ch3), Ct, V, slope, ptr(t), ptr(part), stream()),
+        check(L.dpi_chain_add_stats_io(ptr(r1), ptr(ch1), ptr(r3), ptr(ch3), Ct, V, slope, ptr(t), ptr(part), _io(r3), stream()),
               "dpi_chain_add_stats")
         B = rp.bn
         raw_bn_finalize(part, nblk, Ct, V, gB, eB, slope, B.running_mean, B.running_var, B.num_batches_tracked, miB, chB,
@@ -695,7 +749,7 @@ class ResPath3dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        dy = _req(dy, "respath grad")
+        dy = _req(dy, "respath grad", act=True)
         x, r3, r1, t, mi3, mi1, miB = ctx.saved_tensors[:7]
         it = iter(ctx.saved_tensors[7:])
         (w3, b3, g3, e3, w1, b1, g1, e1, gB, eB) = [None if isnone else next(it) for isnone in ctx.none_mask]
@@ -726,19 +780,22 @@ class SkipJoinFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, deep, rp, slope, linear, *p):
-        x, deep = _req(x, "skip input"), _req(deep, "deep input")
+        x, deep = _req(x, "skip input", act=True), _req(deep, "deep input", act=True)
         (w3, b3, g3, e3, w1, b1, g1, e1, gB, eB) = p
         L = _lib.load()
         f32 = dict(dtype=torch.float32, device=x.device)
+        adt = act_dtype()
+        if deep.dtype != adt:
+            raise _lib.DpiError("skip_join: the up-sampled branch is %s, this node stores %s (storage mode switched between nodes?)" % (deep.dtype, adt))
         Cs = w3.shape[0]
         Cd, Dd, Hd, Wd = _dims(deep)
         bn3_, bn1_ = rp.conv3x3._parts()[1], rp.conv1x1._parts()[1]
-        d3, d1 = make_desc(x, w3, 1), make_desc(x, w1, 1)
+        d3, d1 = make_desc(x, w3, 1, adt), make_desc(x, w1, 1, adt)
         Do, Ho, Wo = desc_out_dims(d3)
         if not (Do <= 2 * Dd and Ho <= 2 * Hd and Wo <= 2 * Wd):
             raise _lib.DpiError("skip_join: the up-sampled branch is smaller than the skip branch")
         V = Do * Ho * Wo
-        r3 = torch.empty(_like_spatial(x, Cs, Do, Ho, Wo), **f32)
+        r3 = torch.empty(_like_spatial(x, Cs, Do, Ho, Wo), dtype=adt, device=x.device)
         r1 = torch.empty_like(r3)
         mi3, mi1, miB = (torch.empty(2 * Cs, **f32) for _ in range(3))
         ch3, ch1, chB = (torch.empty(5 * Cs, **f32) for _ in range(3))
@@ -747,35 +804,35 @@ class SkipJoinFn(torch.autograd.Function):
         t = torch.empty_like(r3)
         nblk = L.dpi_stat_blocks(Cs, V)
         part = torch.empty(nblk * Cs * 2, dtype=torch.float64, device=x.device)
-        check(L.dpi_chain_add_stats(ptr(r1), ptr(ch1), ptr(r3), ptr(ch3), Cs, V, slope, ptr(t), ptr(part), stream()),
+        check(L.dpi_chain_add_stats_io(ptr(r1), ptr(ch1), ptr(r3), ptr(ch3), Cs, V, slope, ptr(t), ptr(part), _io(r3), stream()),
               "dpi_chain_add_stats")
         B = rp.bn
         raw_bn_finalize(part, nblk, Cs, V, gB, eB, slope, B.running_mean, B.running_var, B.num_batches_tracked, miB, chB,
                         act_first=1)
-        cat = torch.empty(_like_spatial(x, Cs + Cd, Do, Ho, Wo), **f32)
+        cat = torch.empty(_like_spatial(x, Cs + Cd, Do, Ho, Wo), dtype=adt, device=x.device)
         raw_chain_apply(t, chB, Cs, V, cat[:, :Cs])
-        check(L.dpi_upsample2x_fwd(ptr(deep), None, Cd, Dd, Hd, Wd, Do, Ho, Wo, int(linear), ptr(cat[:, Cs:]), stream()),
+        check(L.dpi_upsample2x_fwd_io(ptr(deep), None, Cd, Dd, Hd, Wd, Do, Ho, Wo, int(linear), ptr(cat[:, Cs:]), _io(deep), stream()),
               "dpi_upsample2x_fwd")
         ctx.save_for_backward(x, r3, r1, t, mi3, mi1, miB, *[q for q in p if q is not None])
         ctx.none_mask = [q is None for q in p]
         ctx.descs = (d3, d1)
         ctx.slope = float(slope)
-        ctx.up = (Cs, Cd, Dd, Hd, Wd, Do, Ho, Wo, int(linear), deep.shape)
+        ctx.up = (Cs, Cd, Dd, Hd, Wd, Do, Ho, Wo, int(linear), deep.shape, deep.dtype)
         return cat
 
     @staticmethod
     def backward(ctx, dcat):
-        dcat = _req(dcat, "skip-join grad")
+        dcat = _req(dcat, "skip-join grad", act=True)
         x, r3, r1, t, mi3, mi1, miB = ctx.saved_tensors[:7]
         it = iter(ctx.saved_tensors[7:])
         (w3, b3, g3, e3, w1, b1, g1, e1, gB, eB) = [None if isnone else next(it) for isnone in ctx.none_mask]
         d3, d1 = ctx.descs
         slope = ctx.slope
-        Cs, Cd, Dd, Hd, Wd, Do, Ho, Wo, linear, deep_shape = ctx.up
+        Cs, Cd, Dd, Hd, Wd, Do, Ho, Wo, linear, deep_shape, deep_dtype = ctx.up
         L = _lib.load()
         ddeep = None
         if ctx.needs_input_grad[1]:
-            ddeep = torch.empty(deep_shape, dtype=torch.float32, device=dcat.device)
+            ddeep = torch.empty(deep_shape, dtype=deep_dtype, device=dcat.device)
             raw_upsample2x_bwd(dcat[:, Cs:], Cd, Dd, Hd, Wd, Do, Ho, Wo, linear, ddeep)
         dt, dgB, deB, (red3, red1) = _bn_backward_fork(dcat[:, :Cs], t, miB, gB, eB, slope, 1.0,
                                                        [(r3, mi3, g3, e3, None, slope), (r1, mi1, g1, e1, None, slope)])

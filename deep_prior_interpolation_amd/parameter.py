@@ -73,8 +73,10 @@ _FLAGS = [
     (("--earlystop_patience",), dict(type=int, required=False, help="Early stopping patience")),
     (("--earlystop_min_delta",), dict(type=float, required=False, default=1.0, help="Early stopping min percentage delta")),
     # mixed precision (ours; BASELINE configs[4]): bf16 operands / fp32 accumulate in the 3x3(x3) convolutions, everything else fp32
-    (("--precision",), dict(type=str, required=False, default="fp32", choices=["fp32", "bf16", "split"],
-                          help="Arithmetic of the 3x3 convolutions: fp32 (reference), bf16 operands, or the fp32-accurate three-term bf16 split")),
+    (("--precision",), dict(type=str, required=False, default="fp32", choices=["fp32", "bf16", "bf16mm", "split"],
+                          help="fp32 (reference); bf16 = BASELINE configs[4]: activations and their gradients STORED as bf16 (3-D MultiRes-UNet), "
+                               "bf16 operands in the 3x3x3 convolutions, fp32 accumulation / master weights / BatchNorm statistics / Adam; "
+                               "bf16mm = bf16 operands only, fp32 storage; split = fp32-accurate three-term bf16 split")),
     # anti-aliasing add-on (ours: the reference ships operators/ + utils/slopes.py without a caller)
     (("--aa_weight",), dict(type=float, required=False, default=0.0, help="Weight of the directional-Laplacian regulariser (0 = off)")),
     (("--aa_smooth",), dict(type=float, required=False, default=2.0, help="Gaussian smoothing (std, samples) of the structure tensor")),

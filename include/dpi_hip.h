@@ -43,8 +43,10 @@ extern "C" {
 #define DPI_CHAIN_STRIDE 5
 
 const char* dpi_last_error(void);
-/* ABI version: 300 = round 3 (dpi_conv_desc carries its own size as first field), 301 adds dpi_conv_fwd_ws / dpi_conv_bwd_data_ws / dpi_conv_bwd_data_dual.  A binding checks `>=` the version it was
- * written against and dpi_conv_desc_size() == its own struct size. */
+/* ABI version: 300 = round 3 (dpi_conv_desc carries its own size as first field), 301 adds dpi_conv_fwd_ws / dpi_conv_bwd_data_ws /
+ * dpi_conv_bwd_data_dual, 400 = round 4: dpi_conv_desc grows the `io` field (bf16 storage of activations) and the elementwise entry
+ * points get `_io` twins that take the storage types of their tensors.  A binding checks `>=` the version it was written against and
+ * dpi_conv_desc_size() == its own struct size. */
 int dpi_version(void);
 /* Number of devices / properties as HIP sees them (no torch involved). */
 int dpi_device_info(int device, int* cus, int* lds_bytes, size_t* hbm_bytes, char* name, int name_len);
@@ -80,7 +82,18 @@ typedef struct {
    * 2: "split" mode — forward / backward-data operands are split exactly into three bf16 terms and six partial products are
    * accumulated in fp32: fp32-class accuracy (same tolerance as precision 0 against the fp64 oracle) on the bf16 matrix cores. */
   int precision;
+  /* ABI 400: storage type of the ACTIVATION tensors of this layer in HBM, a mask of DPI_IO_*: bit set = that tensor is bf16
+   * (2 bytes per element, same [C][D][H][W] layout), clear = fp32.  The pointer arguments keep their `float*` spelling; with a bit
+   * set the library reads / writes that tensor as bf16: widened exactly on load, rounded to nearest-even on store, all arithmetic
+   * and accumulation in fp32 (BASELINE configs[4]: "bf16 activations + fp32 Adam master weights").  Weights, biases, weight
+   * gradients, chains and statistic partials are always fp32 / double.  BatchNorm partials emitted by dpi_conv_fwd describe the
+   * stored (rounded) output.  0 = every tensor fp32 (the reference's storage, main.py:112). */
+  int io;
 } dpi_conv_desc;
+#define DPI_IO_X_BF16 1   /* x: input of dpi_conv_fwd / dpi_conv_bwd_weight */
+#define DPI_IO_Y_BF16 2   /* y: output of dpi_conv_fwd */
+#define DPI_IO_DY_BF16 4  /* dy: input of dpi_conv_bwd_data / dpi_conv_bwd_weight */
+#define DPI_IO_DX_BF16 8  /* dx: output (and, with accumulate, input) of dpi_conv_bwd_data */
 /* sizeof(dpi_conv_desc) as the library was compiled; a binding asserts it equals its own struct size at load time. */
 int dpi_conv_desc_size(void);
 
@@ -212,6 +225,48 @@ int dpi_act_bwd(const float* dy, const float* y, size_t n, int kind, float* dx, 
 int dpi_add(const float* a, const float* b, size_t n, float* y, void* stream);
 /* per-channel sum: out[c] = sum_v x[c][v]   (bias gradients) ; ws: double[dpi_stat_blocks*C*2] */
 int dpi_channel_sum(const float* x, int C, size_t V, double* ws, float* out, void* stream);
+
+/* ---------------------------------------------------------------- bf16 storage of activations (ABI 400) ---------
+ * `_io` twins of the entry points above that read or write activation tensors.  `io` says how those tensors live in HBM:
+ *   DPI_STORE_FWD_BF16   the FORWARD tensors of the call (activations: conv outputs, join results, block outputs) are bf16
+ *   DPI_STORE_GRAD_BF16  the GRADIENT tensors of the call (dy, dx: gradients of such activations) are bf16
+ * Per call, [F] / [G] below mark which arguments each bit covers.  Everything else — chains, mean / invstd, gamma / beta and their
+ * gradients, statistic partials (double), workspaces — keeps its type.  Arithmetic is fp32 (double for the reductions); a bf16 element
+ * is widened exactly on load and a result is rounded to nearest-even on store; statistics emitted together with a stored tensor
+ * describe the ROUNDED values.  io = 0 is the fp32 entry point.  Unknown bits are rejected (DPI_E_ARG). */
+#define DPI_STORE_FWD_BF16 1u
+#define DPI_STORE_GRAD_BF16 2u
+int dpi_channel_stats_io(const float* x /*F*/, const float* chain, int C, size_t V, double* partials, unsigned io, void* stream);
+int dpi_chain_apply_io(const float* x /*F*/, const float* chain, int C, size_t V, float* y /*F*/, unsigned io, void* stream);
+int dpi_chain_add_stats_io(const float* a /*F*/, const float* chain_a, const float* b /*F*/, const float* chain_b, int C, size_t V,
+                           float slope, float* t /*F*/, double* partials, unsigned io, void* stream);
+int dpi_bn_bwd_reduce_io(const float* dy /*G*/, const float* x /*F*/, const float* mean_invstd, const float* gamma, const float* beta,
+                         const float* in_chain, float pre_slope, float post_slope, int C, size_t V, double* partials, unsigned io,
+                         void* stream);
+int dpi_bn_bwd_apply_io(const float* dy /*G*/, const float* x /*F*/, const float* mean_invstd, const float* gamma, const float* beta,
+                        const float* in_chain, float pre_slope, float post_slope, const double* partials, int nblk, int C, size_t V,
+                        float* dx /*G*/, float* dgamma, float* dbeta, unsigned io, void* stream);
+int dpi_bn_bwd_apply_fork_io(const float* dy /*G*/, const float* x /*F*/, const float* mean_invstd, const float* gamma, const float* beta,
+                             const float* in_chain, float pre_slope, float post_slope, const double* partials, int nblk, int C,
+                             size_t V, float* dx /*G*/, float* dgamma, float* dbeta, const float* xa /*F*/, const float* mi_a,
+                             const float* gamma_a, const float* beta_a, const float* chain_a, float post_a, double* partials_a,
+                             const float* xb /*F*/, const float* mi_b, const float* gamma_b, const float* beta_b, const float* chain_b,
+                             float post_b, double* partials_b, unsigned io, void* stream);
+int dpi_bn_bwd_apply_dual_io(const float* dy /*G*/, int nblk, int C, size_t V, const float* xa /*F*/, const float* mi_a,
+                             const float* gamma_a, const float* beta_a, const float* chain_a, float post_a,
+                             const double* partials_a, float* dxa /*G*/, float* dgamma_a, float* dbeta_a, const float* xb /*F*/,
+                             const float* mi_b, const float* gamma_b, const float* beta_b, const float* chain_b,
+                             float post_b, const double* partials_b, float* dxb /*G*/, float* dgamma_b, float* dbeta_b,
+                             int f_lo, int f_hi, const float* f_mi, const float* f_gamma, const float* f_beta,
+                             float f_post, double* f_partials, unsigned io, void* stream);
+int dpi_upsample2x_fwd_io(const float* x /*F*/, const float* chain, int C, int D, int H, int W, int Do, int Ho, int Wo, int linear,
+                          float* y /*F*/, unsigned io, void* stream);
+/* ws (fp32, dpi_upsample2x_bwd_ws_floats) keeps its type */
+int dpi_upsample2x_bwd_io(const float* dy /*G*/, int C, int D, int H, int W, int Do, int Ho, int Wo, int linear, float* dx /*G*/,
+                          float* ws, unsigned io, void* stream);
+/* z stays fp32 (it is the fixed network input of main.py:62-64); out [F] is the perturbed input the first layers read */
+int dpi_noise_add_io(const float* z, size_t n, float std, uint64_t seed, const uint64_t* step_ptr, float* out /*F*/, unsigned io,
+                     void* stream);
 
 /* ---------------------------------------------------------------- up-sampling / concat ----------
  * Replaces nn.Upsample(scale_factor=2, mode=nearest|bilinear|trilinear, align_corners=False)

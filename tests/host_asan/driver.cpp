@@ -14,15 +14,15 @@
 static int failures = 0;
 #define EXPECT(cond, ...) do { if (!(cond)) { ++failures; std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
 
-static dpi_conv_desc desc(int cin, int cout, int D, int H, int W, int k, int kd, int stride, int precision = 0) {
+static dpi_conv_desc desc(int cin, int cout, int D, int H, int W, int k, int kd, int stride, int precision = 0, int io = 0) {
   dpi_conv_desc d;
   d.size = (int)sizeof(dpi_conv_desc);
-  d.Cin = cin; d.Cout = cout; d.D = D; d.H = H; d.W = W; d.k = k; d.kd = kd; d.stride = stride; d.precision = precision;
+  d.Cin = cin; d.Cout = cout; d.D = D; d.H = H; d.W = W; d.k = k; d.kd = kd; d.stride = stride; d.precision = precision; d.io = io;
   return d;
 }
 
 int main() {
-  EXPECT(dpi_version() >= 301, "version %d", dpi_version());
+  EXPECT(dpi_version() >= 400, "version %d", dpi_version());
   EXPECT(dpi_conv_desc_size() == (int)sizeof(dpi_conv_desc), "desc size");
   // a buffer that is big enough for the few bytes host code may legitimately read from "device" pointers: none — host code must never
   // dereference them, ASAN would flag reads of this 16-byte allocation past its end
@@ -39,7 +39,10 @@ int main() {
         for (int stride : {1, 2})
           for (int prec : {0, 1, 2}) {
             const int kd = sh[0] == 1 ? 1 : k;
-            dpi_conv_desc d = desc(ch[0], ch[1], sh[0], sh[1], sh[2], k, kd, stride, prec);
+            // storage types (ABI 400): fp32 everywhere, and for the fp32 / bf16 arithmetic modes bf16 activations + gradients
+            // (the planners pick other kernels then: no 4x4x1 / pair kernels, the bf16 kernel on every big-tile shape)
+            const int io = (prec < 2 && ((n_desc / 3) & 1)) ? 15 : 0;
+            dpi_conv_desc d = desc(ch[0], ch[1], sh[0], sh[1], sh[2], k, kd, stride, prec, io);
             ++n_desc;
             const bool valid = !(k == 1 && stride == 2);
             const int nblk = dpi_conv_fwd_stat_blocks(&d);

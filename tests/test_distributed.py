@@ -45,11 +45,18 @@ def _worker(rank, world, port, shape, dim, stride, gain, outdir, dynamic=False):
 
         def fn(i, patch):
             # rank 0 is the slow rank, made slow by an explicit hand-shake instead of a sleep ratio (no wall-clock assumption): it
-            # holds its FIRST patch until rank 1 has finished 30 of the 48 — the shared counter must have routed those to rank 1
+            # holds its FIRST patch until rank 1 has finished 30 of the 48 — the shared counter must have routed those to rank 1.
+            # Rank 1 in turn does not finish its first patch before rank 0 holds one (on a loaded box rank 1 could otherwise drain the
+            # whole queue before rank 0's process gets to its first claim, and "rank 0 took at least one" would fail for scheduling reasons)
             if rank == 1:
+                if not state["held"]:
+                    state["held"] = True
+                    while int(store.add("dpi/test/rank0_holding", 0)) < 1:
+                        time.sleep(0.001)
                 store.add("dpi/test/rank1_done", 1)
             elif not state["held"]:
                 state["held"] = True
+                store.add("dpi/test/rank0_holding", 1)
                 while int(store.add("dpi/test/rank1_done", 0)) < 30:
                     time.sleep(0.001)
             return _fake_optimise(i, patch)

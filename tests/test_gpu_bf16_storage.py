@@ -1,0 +1,472 @@
+"""bf16 STORAGE of activations (BASELINE configs[4]: "bf16 activations + fp32 Adam master weights"; ABI 400: dpi_conv_desc.io, the *_io
+entry points).  The reference is fp32-only (main.py:112 `.type(dtype)`), so the oracle statement is: a kernel given bf16 tensors computes,
+in fp32, what the fp64 oracle computes on the WIDENED bf16 values, and what it stores is that result rounded to nearest-even.
+
+ (1) every convolution family (forward, backward-data, backward-weight; fp32-MFMA, bf16-MFMA, 1x1x1, stride 2, VALU fall-backs) on operands
+     that are bf16-representable — products are then exact in every arithmetic mode, so a stored element may differ from the fp64 oracle by
+     half a bf16 ulp (+ the fp32 accumulation error), and weight gradients (fp32 outputs) keep the fp32 kernels' own 5e-6;
+ (2) every elementwise kernel bit-for-bit against round_bf16(fp32 entry point on the widened tensors) — the fp32 entry points are the ones
+     tests/test_gpu_ops.py holds against the reference's golden vectors and the oracle;
+ (3) the fused nodes and the whole loop: storage mode against fp32 storage on the same seed, and a field-scale patch.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dpi_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from deep_prior_interpolation_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(autouse=True)
+def _modes_restored(ops):
+    yield
+    ops.set_precision("fp32")
+    ops.set_storage("fp32")
+
+
+def bf16_values(shape, gen, scale=1.0):
+    """fp32 tensor whose values are exactly bf16-representable."""
+    return (torch.randn(shape, generator=gen) * scale).to(BF).float()
+
+
+def half_ulp_ok(got, ref64, what, slack=0.503):
+    """|got - ref| <= half a bf16 ulp of ref (+ a little for the fp32 accumulation error moving a value across a rounding boundary)."""
+    got = got.detach().float().cpu().double()
+    ref = ref64.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    # ulp of a bf16 value v: 2^(floor(log2|v|) - 7); a tiny absolute term covers results that cancel to ~0 (their fp32 error is absolute)
+    bound = slack * 2.0 ** (torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7) + 2e-6 * ref.abs().max()
+    bad = (got - ref).abs() > bound
+    assert not bad.any(), "%s: %d of %d elements off by more than half a bf16 ulp (worst %.3g vs bound %.3g)" % (
+        what, int(bad.sum()), bad.numel(), float(((got - ref).abs() / bound).max()), 1.0)
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# (1) convolutions
+# cin, cout, shape, k, stride — each row names the kernel the shape reaches with bf16 tensors
+CONV_IO = [
+    (8, 13, (64, 64, 64), 3, 1),      # >= 512 big tiles: conv_bf16_kernel<3,4,2> in bf16 mode, conv_mfma IOB variants in fp32 mode; bf16 bww
+    (25, 16, (32, 64, 64), 3, 1),     # 4m + 1 channels (tap-packed tail variants)
+    (64, 4, (64, 64, 64), 3, 1),      # few output channels: no 4x4x1 / fewco kernel with bf16 tensors -> bf16 kernel / VALU kernel
+    (4, 8, (64, 64, 64), 3, 1),
+    (25, 1, (32, 32, 64), 3, 1),      # the output layer's shape (y fp32 in the net; here bf16 as well)
+    (35, 53, (8, 16, 16), 3, 1),      # coarse level: small-tile conv_mfma, input-channel split off / on below
+    (212, 71, (4, 8, 8), 3, 1),       # input-channel split (workspace) + splitk_reduce_kernel storing bf16
+    (25, 25, (16, 32, 32), 3, 2),     # stride 2: conv_mfma<..,S=2>, conv_bwd_data_s2_mfma, conv_bwd_weight_mfma<..,S=2>
+    (51, 51, (9, 11, 13), 3, 2),      # stride 2, odd sizes
+    (3, 5, (6, 6, 6), 3, 2),          # VALU stride-2 kernels (few channels)
+    (64, 25, (16, 16, 32), 1, 1),     # 1x1x1 MFMA forward / backward-data / backward-weight
+    (137, 51, (5, 7, 9), 1, 1),       # 1x1x1, V not a multiple of 4 (scalar paths)
+    (6, 3, (5, 7, 9), 1, 1),          # 1x1x1 VALU kernels
+    (13, 9, (7, 9, 11), 3, 1),        # odd row lengths: element-wise staging everywhere, dY rows not 8-byte aligned
+    (7, 3, (9, 10, 12), 3, 1),        # VALU forward / backward-weight
+    (13, 4, (32, 32, 40), 3, 1),      # few-output-channel backward-weight kernels (swapped MFMA orientation / smallco)
+]
+
+
+def _conv_case(ops, cin, cout, shape, k, stride, seed):
+    gen = torch.Generator().manual_seed(seed)
+    x = bf16_values((1, cin) + shape, gen)
+    w = bf16_values((cout, cin, k, k, k), gen, 1.0 / np.sqrt(cin * k ** 3))
+    b = bf16_values((cout,), gen)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = O.conv_nd(xr, wr, br, stride)
+    dy = bf16_values(tuple(yr.shape), gen)
+    yr.backward(dy.double())
+    return x, w, b, dy, yr.detach(), xr.grad, wr.grad
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16mm"])
+@pytest.mark.parametrize("cin,cout,shape,k,stride", CONV_IO)
+def test_conv_kernels_with_bf16_tensors_vs_oracle(ops, cin, cout, shape, k, stride, prec):
+    """forward x(bf16) -> y(bf16) with BatchNorm partials of the STORED y, backward-data dy(bf16) -> dx(bf16), backward-data with
+    accumulate (read-modify-write of a bf16 dx), backward-weight (x bf16, dy bf16) -> dw fp32."""
+    ops.set_precision(prec)
+    L = ops._lib.load()
+    x, w, b, dy, yr, dxr, dwr = _conv_case(ops, cin, cout, shape, k, stride, cin * 131 + cout)
+    xg, wg, bg, dyg = x.to(DEV).to(BF), w.to(DEV), b.to(DEV), dy.to(DEV).to(BF)
+    d = ops.make_desc(xg, wg, stride, BF)
+    assert d.io == 15
+    y = torch.empty(yr.shape, dtype=BF, device=DEV)
+    nblk = L.dpi_conv_fwd_stat_blocks(C.byref(d))
+    part = torch.zeros(nblk * cout * 2, dtype=torch.float64, device=DEV)
+    ops.raw_conv_fwd(d, xg, None, wg, bg, y, part)
+    half_ulp_ok(y, yr, "y")
+    # the partials are {sum, sum^2} of what was stored
+    p = part.view(nblk, cout, 2).sum(0).cpu()
+    ys = y.float().double().cpu().reshape(cout, -1)
+    np.testing.assert_allclose(p[:, 0].numpy(), ys.sum(1).numpy(), rtol=1e-9, atol=1e-7 * float(ys.abs().sum(1).max()))
+    np.testing.assert_allclose(p[:, 1].numpy(), (ys * ys).sum(1).numpy(), rtol=1e-9)
+    # backward-data, plain and accumulating into a bf16 destination
+    dx = torch.empty(x.shape, dtype=BF, device=DEV)
+    ops.raw_conv_bwd_data(d, dyg, wg, dx)
+    half_ulp_ok(dx, dxr, "dx")
+    base = bf16_values(tuple(x.shape), torch.Generator().manual_seed(5))
+    dx2 = base.to(DEV).to(BF)
+    ops.raw_conv_bwd_data(d, dyg, wg, dx2, accumulate=True)
+    half_ulp_ok(dx2, dxr + base.double(), "dx (accumulate)")
+    # backward-weight: fp32 output, exact products -> the fp32 kernels' own tolerance
+    dw = torch.empty_like(wg)
+    ops.raw_conv_bwd_weight(d, xg, None, dyg, dw)
+    assert rel(dw, dwr) < 5e-6, rel(dw, dwr)
+
+
+@pytest.mark.parametrize("xbf,ybf", [(True, False), (False, True)])
+@pytest.mark.parametrize("cin,cout,shape,k,stride", [(25, 1, (32, 32, 64), 3, 1), (8, 13, (64, 64, 64), 3, 1), (35, 53, (8, 16, 16), 3, 1),
+                                                     (25, 25, (16, 32, 32), 3, 2), (64, 25, (16, 16, 32), 1, 1), (7, 3, (9, 10, 12), 3, 1)])
+def test_conv_mixed_storage_types(ops, cin, cout, shape, k, stride, xbf, ybf):
+    """One side bf16, the other fp32: the network's first layers (fp32 z when the perturbation is off, bf16 outputs) and its output layer
+    (bf16 input, fp32 output / fp32 incoming gradient, bf16 input gradient)."""
+    ops.set_precision("bf16mm")
+    x, w, b, dy, yr, dxr, dwr = _conv_case(ops, cin, cout, shape, k, stride, cin * 7 + cout)
+    xg = x.to(DEV).to(BF) if xbf else x.to(DEV)
+    dyg = dy.to(DEV).to(BF) if ybf else dy.to(DEV)
+    wg, bg = w.to(DEV), b.to(DEV)
+    d = ops.make_desc(xg, wg, stride, BF if ybf else torch.float32)
+    assert d.io == (9 if xbf else 0) + (6 if ybf else 0)
+    y = torch.empty(yr.shape, dtype=BF if ybf else torch.float32, device=DEV)
+    ops.raw_conv_fwd(d, xg, None, wg, bg, y)
+    if ybf:
+        half_ulp_ok(y, yr, "y")
+    else:
+        assert rel(y, yr) < 2e-6
+    dx = torch.empty(x.shape, dtype=xg.dtype, device=DEV)
+    ops.raw_conv_bwd_data(d, dyg, wg, dx)
+    if xbf:
+        half_ulp_ok(dx, dxr, "dx")
+    else:
+        assert rel(dx, dxr) < 2e-6
+    dw = torch.empty_like(wg)
+    ops.raw_conv_bwd_weight(d, xg, None, dyg, dw)
+    assert rel(dw, dwr) < 5e-6
+
+
+def test_conv_chain_on_bf16_input_and_dual_backward(ops):
+    """The producer's BatchNorm + LeakyReLU chain applied while a bf16 tensor is staged (forward and backward-weight), and the fused
+    input gradient of a 3x3x3 + 1x1x1 pair (dpi_conv_bwd_data_dual: two launches with bf16 tensors, the second accumulating)."""
+    ops.set_precision("bf16mm")
+    gen = torch.Generator().manual_seed(3)
+    cin, c3, c1, shape = 25, 16, 25, (16, 32, 64)
+    x = bf16_values((1, cin) + shape, gen)
+    chain = torch.stack([torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen) * 0.3, torch.full((cin,), 0.2),
+                         torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen) * 0.1], 1).contiguous()
+    w3 = bf16_values((c3, cin, 3, 3, 3), gen, 0.05)
+    w1 = bf16_values((c1, cin, 1, 1, 1), gen, 0.2)
+    xd = x.double()
+    ps, pb, sl, qs, qb = (chain[:, i].double().view(1, cin, 1, 1, 1) for i in range(5))
+    v = ps * xd + pb
+    tx = (qs * torch.where(v > 0, v, v * sl) + qb)
+    # T(x) is NOT bf16-representable: the bf16 arithmetic mode rounds it while staging, so compare the fp32 arithmetic mode tightly ...
+    ops.set_precision("fp32")
+    xg, wg = x.to(DEV).to(BF), w3.to(DEV)
+    d3 = ops.make_desc(xg, wg, 1, BF)
+    y = torch.empty((1, c3) + shape, dtype=BF, device=DEV)
+    ops.raw_conv_fwd(d3, xg, chain.to(DEV), wg, None, y)
+    yr = O.conv_nd(tx, w3.double(), None, 1)
+    half_ulp_ok(y, yr, "y (chain)")
+    dy3 = bf16_values(tuple(yr.shape), gen)
+    dw = torch.empty_like(wg)
+    ops.raw_conv_bwd_weight(d3, xg, chain.to(DEV), dy3.to(DEV).to(BF), dw)
+    txr = tx.clone().requires_grad_(False)
+    wr = w3.double().requires_grad_(True)
+    O.conv_nd(txr, wr, None, 1).backward(dy3.double())
+    assert rel(dw, wr.grad) < 5e-6
+    # ... and the bf16 arithmetic mode at its operand rounding (2^-9 per staged element)
+    ops.set_precision("bf16mm")
+    d3b = ops.make_desc(xg, wg, 1, BF)
+    ops.raw_conv_fwd(d3b, xg, chain.to(DEV), wg, None, y)
+    assert rel(y.float(), yr) < 4e-3
+    # dual backward-data
+    dy1 = bf16_values((1, c1) + shape, gen)
+    d1 = ops.make_desc(xg, w1.to(DEV), 1, BF)
+    dx = torch.empty((1, cin) + shape, dtype=BF, device=DEV)
+    ops.raw_conv_bwd_data_dual(d3b, dy3.to(DEV).to(BF), wg, d1, dy1.to(DEV).to(BF), w1.to(DEV), dx)
+    xr = x.double().requires_grad_(True)
+    (O.conv_nd(xr, w3.double(), None, 1) * dy3.double()).sum().backward()
+    g3 = xr.grad.clone()
+    xr.grad = None
+    (O.conv_nd(xr, w1.double(), None, 1) * dy1.double()).sum().backward()
+    # two stores (the 1x1x1 launch rounds, the 3x3x3 launch adds and rounds again): one bf16 ulp
+    half_ulp_ok(dx, g3 + xr.grad, "dx (dual)", slack=1.01)
+
+
+def test_unknown_io_bits_are_rejected(ops):
+    L = ops._lib.load()
+    x = torch.zeros((1, 4, 4, 4, 4), device=DEV)
+    w = torch.zeros((4, 4, 3, 3, 3), device=DEV)
+    d = ops.make_desc(x, w, 1)
+    d.io = 16
+    assert L.dpi_conv_fwd(C.byref(d), x.data_ptr(), None, w.data_ptr(), None, x.data_ptr(), None, None) < 0
+    assert L.dpi_chain_apply_io(x.data_ptr(), None, 4, 64, x.data_ptr(), 4, None) < 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# (2) elementwise kernels: bf16 entry == round_bf16(fp32 entry on the widened tensors), bit for bit
+def _chain(C_, gen):
+    return torch.stack([torch.rand(C_, generator=gen) + 0.5, torch.randn(C_, generator=gen) * 0.3, torch.full((C_,), 0.2),
+                        torch.rand(C_, generator=gen) + 0.5, torch.randn(C_, generator=gen) * 0.1], 1).contiguous().to(DEV)
+
+
+def _bits_equal(a_bf16, b_f32, what):
+    """a (bf16 tensor) == round-to-nearest-even(b) exactly."""
+    assert a_bf16.dtype == BF
+    exp = b_f32.to(BF)
+    same = a_bf16.view(torch.int16) == exp.view(torch.int16)
+    assert bool(same.all()), "%s: %d of %d elements differ from round_bf16(fp32 path)" % (what, int((~same).sum()), same.numel())
+
+
+@pytest.mark.parametrize("C_,shape", [(5, (6, 8, 12)), (3, (5, 7, 9)), (13, (16, 16, 32))])
+def test_chain_apply_add_stats_and_channel_stats_bf16(ops, C_, shape):
+    from deep_prior_interpolation_amd._lib import check, load, ptr, stream
+    L = load()
+    gen = torch.Generator().manual_seed(C_)
+    V = int(np.prod(shape))
+    a, b = (bf16_values((1, C_) + shape, gen).to(DEV) for _ in range(2))
+    cha, chb = _chain(C_, gen), _chain(C_, gen)
+    ab, bb = a.to(BF), b.to(BF)
+    # chain_apply
+    y32 = torch.empty_like(a)
+    ops.raw_chain_apply(a, cha, C_, V, y32)
+    y16 = torch.empty_like(ab)
+    ops.raw_chain_apply(ab, cha, C_, V, y16)
+    _bits_equal(y16, y32, "chain_apply")
+    # channel statistics of T(x) read from a bf16 tensor == read from its widened copy
+    nblk = L.dpi_stat_blocks(C_, V)
+    p32 = torch.zeros(nblk * C_ * 2, dtype=torch.float64, device=DEV)
+    p16 = torch.zeros_like(p32)
+    check(L.dpi_channel_stats_io(ptr(a), ptr(cha), C_, V, ptr(p32), 0, stream()))
+    check(L.dpi_channel_stats_io(ptr(ab), ptr(cha), C_, V, ptr(p16), 1, stream()))
+    assert torch.equal(p32, p16)
+    # residual join: t stored as bf16, statistics of act(stored t)
+    t32, t16 = torch.empty_like(a), torch.empty_like(ab)
+    q32, q16 = torch.zeros_like(p32), torch.zeros_like(p32)
+    check(L.dpi_chain_add_stats_io(ptr(a), ptr(cha), ptr(b), ptr(chb), C_, V, 0.2, ptr(t32), ptr(q32), 0, stream()))
+    check(L.dpi_chain_add_stats_io(ptr(ab), ptr(cha), ptr(bb), ptr(chb), C_, V, 0.2, ptr(t16), ptr(q16), 1, stream()))
+    _bits_equal(t16, t32, "chain_add_stats t")
+    ts = t16.float().double()
+    act = torch.where(ts > 0, ts, ts * 0.2).reshape(C_, -1)
+    got = q16.view(nblk, C_, 2).sum(0)
+    np.testing.assert_allclose(got[:, 0].cpu().numpy(), act.sum(1).cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(got[:, 1].cpu().numpy(), (act * act).sum(1).cpu().numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("C_,shape", [(6, (6, 8, 12)), (3, (5, 7, 9)), (25, (8, 16, 32))])
+def test_batchnorm_backward_kernels_bf16(ops, C_, shape):
+    """reduce / apply / apply_fork / apply_dual with bf16 forward tensors and bf16 gradients: same partials, dx == round(fp32 dx), and the
+    follow-up partials a fork / dual emits describe the STORED (rounded) dx."""
+    from deep_prior_interpolation_amd._lib import load
+    L = load()
+    gen = torch.Generator().manual_seed(C_ + 100)
+    x, xa, xb_, dy = (bf16_values((1, C_) + shape, gen).to(DEV) for _ in range(4))
+    f32 = dict(dtype=torch.float32, device=DEV)
+    gam, bet = torch.rand(C_, generator=gen).to(DEV) + 0.5, torch.randn(C_, generator=gen).to(DEV) * 0.2
+
+    def mi_of(t):
+        m = t.double().reshape(C_, -1).mean(1)
+        v = t.double().reshape(C_, -1).var(1, unbiased=False)
+        return torch.cat([m, 1.0 / torch.sqrt(v + 1e-5)]).float().to(DEV)
+    mi, mia, mib = mi_of(x), mi_of(xa), mi_of(xb_)
+    b16 = lambda t: t.to(BF)
+    # plain two-phase backward
+    dx32, dg32, db32 = ops._bn_backward(dy, x, mi, gam, bet, 1.0, 0.2)
+    dx16, dg16, db16 = ops._bn_backward(b16(dy), b16(x), mi, gam, bet, 1.0, 0.2)
+    _bits_equal(dx16, dx32, "bn_bwd_apply dx")
+    assert torch.equal(dg32, dg16) and torch.equal(db32, db16)
+    # fork: dx feeds two more BatchNorms; their partials must equal a reduce pass over the stored dx
+    forks32 = [(xa, mia, gam, bet, None, 0.2), (xb_, mib, gam, bet, None, 1.0)]
+    forks16 = [(b16(xa), mia, gam, bet, None, 0.2), (b16(xb_), mib, gam, bet, None, 1.0)]
+    dt32, _, _, reds32 = ops._bn_backward_fork(dy, x, mi, gam, bet, 0.2, 1.0, forks32)
+    dt16, _, _, reds16 = ops._bn_backward_fork(b16(dy), b16(x), mi, gam, bet, 0.2, 1.0, forks16)
+    _bits_equal(dt16, dt32, "bn_bwd_apply_fork dx")
+    for (xk, mik, gk, ek, _, postk), (nblk, got) in zip(forks16, reds16):
+        # phase-2 driven by those partials == phase-2 after an explicit reduce over the stored gradient
+        a1 = ops._bn_backward_apply(dt16, xk, mik, gk, ek, 1.0, postk, (nblk, got))
+        a2 = ops._bn_backward(dt16, xk, mik, gk, ek, 1.0, postk)
+        assert torch.equal(a1[0].view(torch.int16), a2[0].view(torch.int16))
+        np.testing.assert_allclose(a1[1].cpu().numpy(), a2[1].cpu().numpy(), rtol=2e-5, atol=1e-5)
+    # dual: two sides share the incoming gradient, third BatchNorm forked off side b on a channel range
+    lo, hi = 1, C_ - 1
+    mif = mi_of(xb_[:, lo:hi])
+    (da32, _, _), (db32_, _, _), _ = ops._bn_backward_apply_dual(dt32, (xa, mia, gam, bet, None, 0.2, reds32[0]), (xb_, mib, gam, bet, None, 1.0, reds32[1]),
+                                                                fork=(lo, hi, mif, gam[lo:hi].contiguous(), bet[lo:hi].contiguous(), 0.2))
+    (da16, _, _), (db16_, _, _), redf = ops._bn_backward_apply_dual(dt16, (b16(xa), mia, gam, bet, None, 0.2, reds16[0]), (b16(xb_), mib, gam, bet, None, 1.0, reds16[1]),
+                                                                   fork=(lo, hi, mif, gam[lo:hi].contiguous(), bet[lo:hi].contiguous(), 0.2))
+    # (the dual's inputs differ between the two runs by the rounding of dt and of the fork partials: compare against the fp32 entry point
+    #  fed with the widened bf16 inputs of the bf16 run instead)
+    (da_w, _, _), (db_w, _, _), _ = ops._bn_backward_apply_dual(dt16.float(), (xa, mia, gam, bet, None, 0.2, reds16[0]), (xb_, mib, gam, bet, None, 1.0, reds16[1]))
+    _bits_equal(da16, da_w, "bn_bwd_apply_dual dxa")
+    _bits_equal(db16_, db_w, "bn_bwd_apply_dual dxb")
+    g1 = ops._bn_backward_apply(db16_[:, lo:hi], b16(xb_)[:, lo:hi], mif, gam[lo:hi].contiguous(), bet[lo:hi].contiguous(), 1.0, 0.2, redf)
+    g2 = ops._bn_backward(db16_[:, lo:hi].contiguous(), b16(xb_)[:, lo:hi].contiguous(), mif, gam[lo:hi].contiguous(), bet[lo:hi].contiguous(), 1.0, 0.2)
+    assert torch.equal(g1[0].view(torch.int16), g2[0].view(torch.int16))
+    del L, f32
+
+
+@pytest.mark.parametrize("linear", [0, 1])
+@pytest.mark.parametrize("C_,shape,crop", [(3, (4, 6, 8), (0, 0, 0)), (5, (3, 5, 7), (1, 1, 1)), (2, (8, 8, 16), (0, 1, 0))])
+def test_upsample_forward_and_adjoint_bf16(ops, C_, shape, crop, linear):
+    from deep_prior_interpolation_amd._lib import check, load, ptr, stream
+    L = load()
+    gen = torch.Generator().manual_seed(11)
+    D, H, W = shape
+    Do, Ho, Wo = 2 * D - crop[0], 2 * H - crop[1], 2 * W - crop[2]
+    x = bf16_values((1, C_) + shape, gen).to(DEV)
+    y32 = torch.empty((1, C_, Do, Ho, Wo), device=DEV)
+    y16 = torch.empty_like(y32, dtype=BF)
+    check(L.dpi_upsample2x_fwd_io(ptr(x), None, C_, D, H, W, Do, Ho, Wo, linear, ptr(y32), 0, stream()))
+    check(L.dpi_upsample2x_fwd_io(ptr(x.to(BF)), None, C_, D, H, W, Do, Ho, Wo, linear, ptr(y16), 1, stream()))
+    _bits_equal(y16, y32, "upsample fwd")
+    dy = bf16_values(tuple(y32.shape), gen).to(DEV)
+    dx32 = torch.empty_like(x)
+    dx16 = torch.empty_like(x, dtype=BF)
+    ops.raw_upsample2x_bwd(dy, C_, D, H, W, Do, Ho, Wo, linear, dx32)
+    ops.raw_upsample2x_bwd(dy.to(BF), C_, D, H, W, Do, Ho, Wo, linear, dx16)
+    _bits_equal(dx16, dx32, "upsample bwd")
+    # and without the workspace (gather kernels)
+    dx16b = torch.empty_like(dx16)
+    check(L.dpi_upsample2x_bwd_io(ptr(dy.to(BF)), C_, D, H, W, Do, Ho, Wo, linear, ptr(dx16b), None, 2, stream()))
+    dx32b = torch.empty_like(dx32)
+    check(L.dpi_upsample2x_bwd_io(ptr(dy), C_, D, H, W, Do, Ho, Wo, linear, ptr(dx32b), None, 0, stream()))
+    _bits_equal(dx16b, dx32b, "upsample bwd (gather)")
+
+
+def test_noise_add_writes_the_same_stream_as_bf16():
+    from deep_prior_interpolation_amd._lib import check, load, ptr, stream
+    L = load()
+    for n in (4096, 4099):
+        z = torch.randn(n, device=DEV)
+        step = torch.tensor([7], dtype=torch.int64, device=DEV)
+        o32 = torch.empty(n, device=DEV)
+        o16 = torch.empty(n, dtype=BF, device=DEV)
+        check(L.dpi_noise_add_io(ptr(z), n, 0.03, 5, ptr(step), ptr(o32), 0, stream()))
+        check(L.dpi_noise_add_io(ptr(z), n, 0.03, 5, ptr(step), ptr(o16), 1, stream()))
+        _bits_equal(o16, o32, "noise_add")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# (3) fused nodes and the loop
+def _net_run(shape, precision, epochs, seed=3, inputdepth=16, extra=()):
+    from deep_prior_interpolation_amd import utils as u
+    from deep_prior_interpolation_amd.main import Interpolator
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    vol = u.hyperbolic_volume(shape, seed=seed)
+    mask = u.random_trace_mask(shape, 0.5, seed=seed + 1)
+    args = parse_arguments(["--imgdir", "synthetic", "--datadim", "3d", "--net", "multiunet", "--inputdepth", str(inputdepth), "--upsample", "linear",
+                            "--loss", "mae", "--lr", "1e-3", "--gain", "40", "--epochs", str(epochs), "--gpu", "0", "--precision", precision] + list(extra))
+    u.set_seed(7)
+    T = Interpolator(args, "/tmp", seed=7)
+    T.load_data({"image": (vol.astype(np.float64) * 40)[..., None], "mask": mask.astype(np.float64)[..., None], "name": "0"})
+    T.build_model()
+    T.build_input()
+    return T
+
+
+@pytest.mark.parametrize("shape", [(32, 32, 64), (20, 18, 36), (17, 19, 22)])
+def test_one_iteration_in_storage_mode_against_fp32_storage(ops, shape):
+    """Same weights, same perturbed input: forward output, loss and every weight gradient of the default MulResUnet3D with bf16 activations
+    against fp32 storage.  Ten block levels of bf16 rounding (2^-9 each, random sign): output within 2 %, loss within 0.5 %, every weight
+    gradient tensor within 10 % in norm with cosine > 0.99.  Also checks that the storage mode really is on: bf16 tensors between nodes."""
+    seen = []
+    T32 = _net_run(shape, "fp32", 1)
+    T16 = _net_run(shape, "bf16", 1)
+    T16.net.load_state_dict(T32.net.state_dict())
+    z = T32.input_.clone()
+    out = {}
+    for name, T in (("fp32", T32), ("bf16", T16)):
+        T.apply_precision()
+        assert ops.STORAGE_BF16 == (name == "bf16")
+        hooks = [m.register_forward_hook(lambda mod, i, o: seen.append((name, o.dtype))) for m in T.net.modules() if type(m).__name__ == "MultiResBlock"]
+        T.net.zero_grad()
+        o = T.net(z.to(BF) if name == "bf16" else z)
+        loss, _ = ops.masked_loss(o, T.img_, T.mask_, "mae")
+        loss.backward()
+        for h in hooks:
+            h.remove()
+        out[name] = (o.detach().clone(), float(loss), {k: p.grad.detach().clone() for k, p in T.net.named_parameters() if p.grad is not None})
+    assert {d for n, d in seen if n == "bf16"} == {BF} and {d for n, d in seen if n == "fp32"} == {torch.float32}
+    o32, l32, g32 = out["fp32"]
+    o16, l16, g16 = out["bf16"]
+    assert o16.dtype == torch.float32
+    assert rel(o16, o32) < 2e-2, rel(o16, o32)
+    assert abs(l16 - l32) < 5e-3 * abs(l32)
+    assert g16.keys() == g32.keys()
+    worst = 0.0
+    for k in g32:
+        a, b = g16[k].double().flatten(), g32[k].double().flatten()
+        if float(b.norm()) < 1e-12:
+            continue
+        cos = float((a @ b) / (a.norm() * b.norm()))
+        worst = max(worst, rel(g16[k], g32[k]))
+        assert cos > 0.99 and rel(g16[k], g32[k]) < 0.1, (k, cos, rel(g16[k], g32[k]))
+    print(shape, "output rel", rel(o16, o32), "loss", l32, l16, "worst gradient rel", worst)
+
+
+def test_loop_in_storage_mode_eager_and_graph_agree_and_converge(ops):
+    """Interpolator.optimize with --precision bf16 (storage mode): the captured-graph loop reproduces the eager loop bit for bit, both
+    stay finite and reach the fp32 run's loss level."""
+    shape = (32, 32, 32)
+    runs = {}
+    for prec, mode in (("fp32", "eager"), ("bf16", "eager"), ("bf16", "graph")):
+        T = _net_run(shape, prec, 40)
+        T.optimize(verbose=False, mode=mode)
+        runs[(prec, mode)] = np.array(T.history.loss)
+        assert np.isfinite(runs[(prec, mode)]).all() and np.isfinite(np.asarray(T.out_best)).all()
+    np.testing.assert_array_equal(runs[("bf16", "eager")], runs[("bf16", "graph")])
+    ref, got = runs[("fp32", "eager")], runs[("bf16", "eager")]
+    assert abs(got[0] - ref[0]) < 1e-2 * ref[0]
+    assert got[-1] < 0.8 * got[0] and abs(got[-1] - ref[-1]) < 0.15 * ref[-1], (ref[-1], got[-1])
+
+
+def test_nets_without_fused_3d_nodes_keep_fp32_storage(ops):
+    """--precision bf16 on a net the storage mode is not built for (2-D MulResUnet, ELU activation): operand rounding only, fp32 tensors."""
+    from deep_prior_interpolation_amd import utils as u
+    from deep_prior_interpolation_amd.main import Interpolator
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    T = _net_run((16, 16, 16), "bf16", 2, extra=["--activation", "ELU"])
+    assert not T.storage_bf16_ok()
+    T.optimize(verbose=False)
+    assert not ops.STORAGE_BF16 and np.isfinite(T.history.loss).all()
+    args = parse_arguments(["--imgdir", "x", "--datadim", "2d", "--filters", "4", "8", "--skip", "4", "--inputdepth", "4", "--epochs", "2", "--gpu", "0",
+                            "--precision", "bf16"])
+    u.set_seed(0)
+    T = Interpolator(args, "/tmp")
+    rng = np.random.RandomState(0)
+    T.load_data({"image": rng.randn(24, 20, 1), "mask": (rng.rand(24, 20, 1) > 0.5).astype(np.float64), "name": "0"})
+    T.build_model()
+    T.build_input()
+    assert not T.storage_bf16_ok()
+    T.optimize(verbose=False)
+    assert np.isfinite(T.history.loss).all()
+
+
+def test_field_scale_patch_runs_in_storage_mode(ops):
+    """configs[4] residency: one 512x256x256 patch (33.5 M voxels, 8 x the bench patch; the default net keeps ~160 GB of fp32 tensors for
+    it, about half of that with bf16 activations) through three Adam iterations of the storage mode; finite, loss not increasing wildly,
+    and the allocator's peak stays below what fp32 storage needs."""
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    T = _net_run((512, 256, 256), "bf16", 3, inputdepth=64)
+    T.optimize(verbose=False, mode="eager")
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    print("512x256x256, bf16 storage: peak %.1f GiB, losses %s, %.2f s / iteration" % (peak, T.history.loss, T.elapsed / 3))
+    assert np.isfinite(T.history.loss).all() and np.isfinite(np.asarray(T.out_best)).all()
+    assert T.history.loss[-1] < 1.5 * T.history.loss[0]
+    assert peak < 130.0
+    del T
+    torch.cuda.empty_cache()

@@ -878,13 +878,16 @@ def test_stale_descriptor_layouts_are_rejected():
     import ctypes as C
     from deep_prior_interpolation_amd import _lib
     L = _lib.load()
-    assert L.dpi_conv_desc_size() == C.sizeof(_lib.ConvDesc) == 40
+    assert L.dpi_conv_desc_size() == C.sizeof(_lib.ConvDesc) == 44
 
     class Old8(C.Structure):
         _fields_ = [(n, C.c_int) for n in ("Cin", "Cout", "D", "H", "W", "k", "kd", "stride")]
 
     class Old9(C.Structure):
         _fields_ = [(n, C.c_int) for n in ("Cin", "Cout", "D", "H", "W", "k", "kd", "stride", "precision")]
+
+    class Abi301(C.Structure):                            # rounds 3: size first, no `io` yet
+        _fields_ = [(n, C.c_int) for n in ("size", "Cin", "Cout", "D", "H", "W", "k", "kd", "stride", "precision")]
     x = torch.randn(1, 4, 4, 8, 8, device=DEV)
     w = torch.randn(8, 4, 3, 3, 3, device=DEV)
     y = torch.full((1, 8, 4, 8, 8), 7.0, device=DEV)
@@ -892,7 +895,7 @@ def test_stale_descriptor_layouts_are_rejected():
     saved = fwd.argtypes
     fwd.argtypes = [C.c_void_p] * 8
     try:
-        for d in (Old8(4, 8, 4, 8, 8, 3, 3, 1), Old9(4, 8, 4, 8, 8, 3, 3, 1, 0)):
+        for d in (Old8(4, 8, 4, 8, 8, 3, 3, 1), Old9(4, 8, 4, 8, 8, 3, 3, 1, 0), Abi301(40, 4, 8, 4, 8, 8, 3, 3, 1, 0)):
             buf = (C.c_char * 64)()                       # the short struct followed by zeros, as it would sit in a caller's frame
             C.memmove(buf, C.byref(d), C.sizeof(d))
             rc = fwd(C.addressof(buf), x.data_ptr(), None, w.data_ptr(), None, y.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
