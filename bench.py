@@ -72,9 +72,10 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--mode", default="auto", choices=["auto", "eager", "graph"])
     ap.add_argument("--patches", type=int, default=12, help="c3: patches per rank taken from the queue (a multiple of --concurrent avoids a part-filled last round)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "split"],
-                    help="bf16: BASELINE configs[4] mixed precision (bf16 MFMA operands in the 3x3x3 convs, fp32 accumulate / storage / Adam); "
-                         "a SECOND bench line, the headline stays fp32")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16mm", "split"],
+                    help="bf16: BASELINE configs[4] mixed precision (activations and their gradients STORED as bf16, bf16 MFMA operands in the 3x3x3 "
+                         "convs, fp32 accumulate / master weights / BatchNorm statistics / Adam); bf16mm: bf16 operands only, fp32 storage (rounds 2-3); "
+                         "each a SECOND bench line, the headline stays fp32")
     ap.add_argument("--concurrent", type=int, default=6, help="c3: patches optimised side by side on one GPU")
     ap.add_argument("--launch-timeout", type=int, default=1800, help="--gpus N without a launcher: seconds before the rank processes are killed")
     a = ap.parse_args()
@@ -470,9 +471,10 @@ def run_c2(a, rank, world, device):
     return {"metric": "Adam iters/sec on 3D MultiRes-UNet (whole job over n_gpus; per_gpu beside it); recon SNR(dB) vs ref under config.snr_vs_reference", "value": round(world * a.steps / dt, 4), "unit": "it/s",
             "per_gpu": round(a.steps / dt, 4),
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "split": "f32 (3 x bf16 split)"}[a.precision], "data": "synthetic",
-            "config": {"workload": {"fp32": "", "bf16": "MIXED PRECISION (bf16 MFMA operands in the 3x3x3 convolutions, fp32 accumulate, fp32 master "
-                                                          "weights / BatchNorm statistics / Adam) — ",
+            "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "bf16mm": "f32 storage, bf16 MFMA operands", "split": "f32 (3 x bf16 split)"}[a.precision], "data": "synthetic",
+            "config": {"workload": {"fp32": "", "bf16": "configs[4] MIXED PRECISION (activations and their gradients stored as bf16 in HBM, bf16 MFMA operands in the "
+                                                          "3x3x3 convolutions, fp32 accumulate, fp32 master weights / weight gradients / BatchNorm statistics / Adam) — ",
+                                   "bf16mm": "bf16 MFMA operands in the 3x3x3 convolutions, fp32 storage and accumulate (the mixed mode of rounds 2-3) — ",
                                    "split": "SPLIT MODE (forward / backward-data operands split exactly into three bf16 terms, six partial products "
                                             "accumulated in fp32: fp32-class accuracy on the bf16 matrix cores) — "}[a.precision] + "configs[1]: MulResUnet3D defaults (5923614 params), patch %dx%dx%d, inputdepth 64, %s, MAE; "
                                    "volume %dx%dx%d (notebook-like hyperbolic stand-in, 66 %% missing traces, std of coarse data %.2f) = %d patches of stride %d pulled "
@@ -563,7 +565,7 @@ def run_c3(a, rank, world, device):
     loop_rate = len(mine) * a.steps / max(timings.get("loop_s", dt), 1e-9)
     return {"metric": "Adam iters/sec on 3D MultiRes-UNet per GPU", "value": round(rate, 3), "unit": "it/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "seconds": round(dt, 3), "higher_is_better": True,
-            "scaling": "strong" if getattr(a, "total_patches", None) else "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "split": "f32 (3 x bf16 split)"}[a.precision], "data": "synthetic",
+            "scaling": "strong" if getattr(a, "total_patches", None) else "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "bf16mm": "f32 storage, bf16 MFMA operands", "split": "f32 (3 x bf16 split)"}[a.precision], "data": "synthetic",
             "config": {"workload": "configs[2]: 256^3 synthetic volume, 50 %% missing traces, %dx%dx%d patches stride %d (%d windows); queue of %d "
                                    "patches (%d per rank unless the queue is fixed) pulled from the shared counter, %d concurrent hipGraph patches per GPU, %d Adam iterations "
                                    "each; timed end to end incl. per-patch set-up, dpi_overlap_add, the all-reduce and normalisation; a step = one "

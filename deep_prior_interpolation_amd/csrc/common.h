@@ -63,6 +63,8 @@ __device__ __forceinline__ float dpi_buffer_load(__amdgpu_buffer_rsrc_t r, int b
 // the *_io entry points); pointers keep their `float*` spelling in the argument structs and are indexed in ELEMENTS through these
 // helpers only.  Statistics that describe a stored tensor (BatchNorm partials in a conv epilogue) are taken of the ROUNDED values.
 typedef float dpi_f32x2 __attribute__((ext_vector_type(2)));
+typedef float dpi_f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned dpi_u32x2v __attribute__((ext_vector_type(2)));
 typedef __bf16 dpi_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dpi_bf16_to_f32(unsigned h) { return __builtin_bit_cast(float, h << 16); }
 __device__ __forceinline__ unsigned dpi_pack_bf16(float lo, float hi) {        // one v_cvt_pk_bf16_f32 (round to nearest even)
@@ -92,15 +94,38 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dpi_buffer_t(const float* base
 __device__ __forceinline__ float dpi_buffer_load_bf16(__amdgpu_buffer_rsrc_t r, int idx) {
   return dpi_bf16_to_f32((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, idx * 2, 0, 0));
 }
+// LOAD NOW, WIDEN LATER.  In a software-pipelined kernel the loads of a whole tile are issued back to back and consumed a phase later.
+// A load that is widened where it is issued (`bits << 16`) needs its data there: inside the `if (bf16) ... else ...` of a run-time flag the
+// wait lands in the branch, every unrolled copy of the branch waits for its own load before the next is issued, and the tile's loads
+// serialise (measured: the staging phase of conv_bf16_kernel and conv_bf16_bwd_weight_kernel 1.5-2.7x slower with HALF the bytes).
+// So the prefetch keeps the raw 16 bits (zero-extended by the load instruction itself, held in the float register bit for bit) and the
+// consumer widens them right before use.
+__device__ __forceinline__ float dpi_buffer_load_bf16_raw(__amdgpu_buffer_rsrc_t r, int idx) {
+  return __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, idx * 2, 0, 0));
+}
+__device__ __forceinline__ float dpi_widen_raw(float raw) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, raw) << 16); }
+// a float4-shaped holder of four raw bf16 (x, y = the two dwords as loaded) -> four floats
+__device__ __forceinline__ float4 dpi_widen_raw4(float4 h) {
+  const unsigned u0 = __builtin_bit_cast(unsigned, h.x), u1 = __builtin_bit_cast(unsigned, h.y);
+  return make_float4(__builtin_bit_cast(float, u0 << 16), __builtin_bit_cast(float, u0 & 0xffff0000u),
+                     __builtin_bit_cast(float, u1 << 16), __builtin_bit_cast(float, u1 & 0xffff0000u));
+}
+// eight raw bytes (four bf16) at element i of a bf16 tensor into such a holder; no ALU work on the data
+__device__ __forceinline__ float4 dpi_ld4_raw_bf16(const float* base, size_t i) {
+  const dpi_u32x2v u = *reinterpret_cast<const dpi_u32x2v*>(reinterpret_cast<const unsigned short*>(base) + i);
+  // (hipcc: __builtin_bit_cast applied to a vector SUBSCRIPT — bit_cast(float, u[1]) — silently yields element 0: the 8-byte load became a
+  //  4-byte load with its dword duplicated.  Copy the elements to scalars first.)
+  const unsigned u0 = u.x, u1 = u.y;
+  return make_float4(__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1), 0.f, 0.f);
+}
 // four consecutive elements starting at element i (i % 4 == 0 and an aligned base: 16-byte / 8-byte accesses)
-typedef float dpi_f32x4v __attribute__((ext_vector_type(4)));
-typedef unsigned dpi_u32x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 dpi_ld4(const float* base, size_t i, bool bf, bool nt) {
   if (bf) {
     const dpi_u32x2v* p = reinterpret_cast<const dpi_u32x2v*>(reinterpret_cast<const unsigned short*>(base) + i);
     const dpi_u32x2v u = nt ? __builtin_nontemporal_load(p) : *p;
-    return make_float4(__builtin_bit_cast(float, u[0] << 16), __builtin_bit_cast(float, u[0] & 0xffff0000u),
-                       __builtin_bit_cast(float, u[1] << 16), __builtin_bit_cast(float, u[1] & 0xffff0000u));
+    const unsigned u0 = u.x, u1 = u.y;
+    return make_float4(__builtin_bit_cast(float, u0 << 16), __builtin_bit_cast(float, u0 & 0xffff0000u),
+                       __builtin_bit_cast(float, u1 << 16), __builtin_bit_cast(float, u1 & 0xffff0000u));
   }
   const dpi_f32x4v* p = reinterpret_cast<const dpi_f32x4v*>(base + i);
   const dpi_f32x4v v = nt ? __builtin_nontemporal_load(p) : *p;
@@ -116,6 +141,18 @@ __device__ __forceinline__ void dpi_st4(float* base, size_t i, float4 v, bool bf
   dpi_f32x4v* p = reinterpret_cast<dpi_f32x4v*>(base + i);
   const dpi_f32x4v w = {v.x, v.y, v.z, v.w};
   if (nt) __builtin_nontemporal_store(w, p); else *p = w;
+}
+// MFMA epilogues hold one voxel per lane (16 consecutive voxels of a row per 16-lane group).  Stored as bf16 that is 2 bytes per lane:
+// twice the store instructions per byte of a float store.  Where element indices are even-aligned (`pairs`, wave-uniform) the even lanes
+// fetch their right neighbour's value (DPP row_shl:1) and store ONE dword for both.  `i` = this lane's element index, `ok` = this lane's
+// element lies inside the tensor (for a pair both do: even row length).  Call from converged code (every lane of the 16-group active).
+__device__ __forceinline__ void dpi_st_bf16_row(float* base, size_t i, float v, bool ok, bool pairs, int lane_in_row) {
+  if (pairs) {
+    const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));   // lane j <- lane j + 1
+    if (ok && !(lane_in_row & 1)) *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(base) + i) = dpi_pack_bf16(v, nb);
+  } else if (ok) {
+    reinterpret_cast<unsigned short*>(base)[i] = dpi_f32_to_bf16(v);
+  }
 }
 // storage types of one convolution launch: input / output tensor of THAT launch (forward: x / y; backward-data: dy / dx)
 static inline bool dpi_io_in(const dpi_conv_desc* d, bool flip) { return (d->io & (flip ? DPI_IO_DY_BF16 : DPI_IO_X_BF16)) != 0; }

@@ -123,17 +123,34 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void conv_bf16_bwd_weight_ker
   auto load_x = [&](int st, int slice) {
     x_live[st] = slice >= 0 && slice < a.D;
     const float* __restrict__ p = dpi_at(xc, (size_t)(x_live[st] ? slice : 0) * HW, a.xb);
+    // (bf16 tensors: raw 8-byte pieces held in .x / .y, widened by store_x — "load now, widen later", common.h; ONE uniform branch
+    //  around the slice's loads)
+    if (a.xb) {
 #pragma unroll
-    for (int e = 0; e < EX; ++e)
-      xr[st][e] = (x_live[st] && xoff[e] >= 0) ? dpi_ld4(p, xoff[e], a.xb, false) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int e = 0; e < EX; ++e)
+        xr[st][e] = (x_live[st] && xoff[e] >= 0) ? dpi_ld4_raw_bf16(p, xoff[e]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EX; ++e)
+        xr[st][e] = (x_live[st] && xoff[e] >= 0) ? *reinterpret_cast<const float4*>(p + xoff[e]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   };
   auto load_dy = [&](int st, int slice) {
     const bool live = slice < d1;
     const float* __restrict__ p = dpi_at(yc, (size_t)(live ? slice : 0) * HW, a.dyb);
+    if (a.dyb) {
 #pragma unroll
-    for (int e = 0; e < EY; ++e) {
-      yr[st][e] = (live && yoff[e] >= 0) ? dpi_ld4(p, yoff[e], a.dyb, false) : make_float4(0.f, 0.f, 0.f, 0.f);
-      hr[st][e] = (live && hdelta != 0 && yoff[e] >= 0) ? dpi_ld(p, yoff[e] + hdelta, a.dyb) : 0.f;
+      for (int e = 0; e < EY; ++e) {
+        yr[st][e] = (live && yoff[e] >= 0) ? dpi_ld4_raw_bf16(p, yoff[e]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        hr[st][e] = (live && hdelta != 0 && yoff[e] >= 0)
+                        ? __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(p)[yoff[e] + hdelta]) : 0.f;     // raw
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EY; ++e) {
+        yr[st][e] = (live && yoff[e] >= 0) ? *reinterpret_cast<const float4*>(p + yoff[e]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        hr[st][e] = (live && hdelta != 0 && yoff[e] >= 0) ? p[yoff[e] + hdelta] : 0.f;
+      }
     }
   };
   auto advance = [&]() {
@@ -164,6 +181,13 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void conv_bf16_bwd_weight_ker
 #pragma unroll
     for (int e = 0; e < EX; ++e) {
       float4 v = xr[0][e];
+      if (a.xb) {
+        if (NS == 1 && !a.chain) {                                 // bf16 in, bf16 operands, no chain: the loaded dwords ARE the packed pairs
+          *reinterpret_cast<u32x2*>(dst + 2 * e * ROWW) = (u32x2){__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y)};
+          continue;
+        }
+        v = dpi_widen_raw4(v);
+      }
       if (a.chain && x_live[0] && xoff[e] >= 0) {                 // zero padding stays zero
         v.x = apply_chain(cx, v.x); v.y = apply_chain(cx, v.y); v.z = apply_chain(cx, v.z); v.w = apply_chain(cx, v.w);
       }
@@ -174,10 +198,11 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void conv_bf16_bwd_weight_ker
     unsigned* __restrict__ dst = dl + (rh * 16 + ch) * 16 + 2 * q;
 #pragma unroll
     for (int e = 0; e < EY; ++e) {
-      const float4 v = yr[0][e];
+      const float4 v = a.dyb ? dpi_widen_raw4(yr[0][e]) : yr[0][e];
+      const float hv = a.dyb ? dpi_widen_raw(hr[0][e]) : hr[0][e];
       float left = from_prev_lane(v.w), right = from_next_lane(v.x);
-      left = q == 0 ? hr[0][e] : left;
-      right = q == 7 ? hr[0][e] : right;
+      left = q == 0 ? hv : left;
+      right = q == 7 ? hv : right;
       unsigned* __restrict__ o = dst + 2 * e * ROWW;
       put(o, DT, v.y, v.z, v.w, right);                        // kw = 0: copy[u] = dY[u + 1]
       put(o + DCOPY, DT, v.x, v.y, v.z, v.w);                  // kw = 1

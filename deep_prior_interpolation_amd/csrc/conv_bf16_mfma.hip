@@ -145,17 +145,22 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
   float sr[8][G::E];                                           // next channel group, raw fp32, in flight
   float wq[G::WE];                                             // next channel group's weights of this thread
   auto load_x = [&](int c0) {
+    if (a.xb) {           // bf16 tensor: ONE uniform branch around the whole group; the raw 16 bits are kept, widened when staged (common.h)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int ci = min(c0 + c, a.Cin - 1);
+        const __amdgpu_buffer_rsrc_t r = dpi_buffer_t(dpi_at(a.x, (size_t)ci * V, true), V, true);
+#pragma unroll
+        for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_buffer_load_bf16_raw(r, goff[e]);
+      }
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int ci = min(c0 + c, a.Cin - 1);                   // channels past Cin: their weights are zero
-      const __amdgpu_buffer_rsrc_t r = dpi_buffer_t(dpi_at(a.x, (size_t)ci * V, a.xb), V, a.xb);
-      if (a.xb) {                                              // bf16 tensor: half the bytes per staged element, widened exactly
+      const __amdgpu_buffer_rsrc_t r = dpi_buffer(a.x + (size_t)ci * V, V * sizeof(float));
 #pragma unroll
-        for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_buffer_load_bf16(r, goff[e]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_buffer_load(r, goff[e] * 4);
-      }
+      for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_buffer_load(r, goff[e] * 4);
     }
   };
   auto load_w = [&](int c0) {
@@ -190,6 +195,14 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
     __syncthreads();                                           // everyone is done reading the previous group
     // registers -> LDS: chain (BN + LeakyReLU of the producer) on in-volume samples, round to bf16, 8 channels per position
     if (!(a.debug & 4)) {
+      // a bf16 tensor without a chain in the bf16 arithmetic mode needs no conversion at all: two raw halves make one packed dword
+      const bool rawpack = NS == 1 && a.xb && !a.chain;
+      if (a.xb && !rawpack) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_widen_raw(sr[c][e]);
+      }
       if (a.chain) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -203,8 +216,13 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
         const int idx = tid + e * 256;
         if ((e + 1) * 256 <= G::TILE || idx < G::TILE) {
           if constexpr (NS == 1) {
-            *reinterpret_cast<u32x4*>(xl + idx * 4) = (u32x4){pack_bf16(sr[0][e], sr[1][e]), pack_bf16(sr[2][e], sr[3][e]),
-                                                              pack_bf16(sr[4][e], sr[5][e]), pack_bf16(sr[6][e], sr[7][e])};
+            if (rawpack) {
+              auto pr = [](float lo, float hi) { return __builtin_bit_cast(unsigned, lo) | (__builtin_bit_cast(unsigned, hi) << 16); };
+              *reinterpret_cast<u32x4*>(xl + idx * 4) = (u32x4){pr(sr[0][e], sr[1][e]), pr(sr[2][e], sr[3][e]), pr(sr[4][e], sr[5][e]), pr(sr[6][e], sr[7][e])};
+            } else {
+              *reinterpret_cast<u32x4*>(xl + idx * 4) = (u32x4){pack_bf16(sr[0][e], sr[1][e]), pack_bf16(sr[2][e], sr[3][e]),
+                                                                pack_bf16(sr[4][e], sr[5][e]), pack_bf16(sr[6][e], sr[7][e])};
+            }
           } else {
             unsigned h[4], m[4], l[4];
 #pragma unroll
@@ -273,11 +291,22 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
     const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
     float* __restrict__ yc = dpi_at(a.y, (size_t)(cok ? co : 0) * Vo + vbase, a.yb);
     double s = 0.0, q = 0.0;
-    if (interior) {
+    if (a.yb) {
+      // bf16 destination: two voxels per dword store where the rows are even-aligned (dpi_st_bf16_row); statistics describe what is stored
+      const bool pairs = !(Wo & 1) && !(Vo & 1) && !((uintptr_t)a.y & 3);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const float v = dpi_stored(acc[t][r] + bv, a.yb);      // statistics describe what is stored
-        dpi_st(yc, (t / NH) * Wo + (t % NH) * 16, v, a.yb);
+        const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
+        const bool ok = interior || (cok && od < Do && oh < Ho && ow < Wo);
+        const float v = dpi_round_bf16(acc[t][r] + bv);
+        dpi_st_bf16_row(yc, (t / NH) * Wo + (t % NH) * 16, v, ok, pairs, lj);
+        if (ok) { s += v; q += (double)v * v; }
+      }
+    } else if (interior) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float v = acc[t][r] + bv;
+        yc[(t / NH) * Wo + (t % NH) * 16] = v;
         if (a.partials) { s += v; q += (double)v * v; }
       }
     } else {
@@ -285,8 +314,8 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
       for (int t = 0; t < NT; ++t) {
         const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
         if (cok && od < Do && oh < Ho && ow < Wo) {
-          const float v = dpi_stored(acc[t][r] + bv, a.yb);
-          dpi_st(yc, (t / NH) * Wo + (t % NH) * 16, v, a.yb);
+          const float v = acc[t][r] + bv;
+          yc[(t / NH) * Wo + (t % NH) * 16] = v;
           s += v;
           q += (double)v * v;
         }

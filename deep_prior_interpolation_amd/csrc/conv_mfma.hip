@@ -115,7 +115,7 @@ __device__ __forceinline__ void stage_load(float (&sr)[4][G::E], const float* __
       const int ci = min(c0 + c, Cin - 1);
       const __amdgpu_buffer_rsrc_t r = dpi_buffer_t(dpi_at(x, (size_t)ci * V, true), V, true);
 #pragma unroll
-      for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_buffer_load_bf16(r, goff[e]);
+      for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_buffer_load_bf16_raw(r, goff[e]);      // raw bits: stage_store widens (common.h)
     }
     return;
   }
@@ -131,8 +131,19 @@ __device__ __forceinline__ void stage_load(float (&sr)[4][G::E], const float* __
 
 // registers -> LDS, applying the per-channel chain to in-volume samples (zero padding stays zero)
 template <class G>
-__device__ __forceinline__ void stage_store(float* lds, const float (&sr)[4][G::E], const float* __restrict__ chain, int Cin, int c0,
-                                            const int (&goff)[G::E], const int (&loff)[G::E]) {
+__device__ __forceinline__ void stage_store(float* lds, const float (&sr_in)[4][G::E], const float* __restrict__ chain, int Cin, int c0,
+                                            const int (&goff)[G::E], const int (&loff)[G::E], bool xb = false) {
+  float sr[4][G::E];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) sr[c][e] = sr_in[c][e];
+  if (xb) {         // the prefetch kept the raw 16 bits of a bf16 tensor (stage_load): widen them here, where the data is consumed anyway
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_widen_raw(sr[c][e]);
+  }
   // ONE wave-uniform branch: without a chain (every backward-data launch, every layer that reads a materialised tensor) the staging is
   // plain stores.  Written as a per-element `chain && in_volume ? T(x) : x`, hipcc evaluated T(x) for every element and selected
   // (5 VALU instructions x 32 elements per tile that compete with the MFMAs of the other waves for the SIMD; round 3).
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
     for (int c0 = c_lo; c0 < cin_main; c0 += 4) {
       __syncthreads();                                   // everyone is done reading the previous chunk
       TRC(2 + (c0 / 4) * 4);
-      stage_store<G>(lds, sr, a.chain, a.Cin, c0, goff, loff);
+      stage_store<G>(lds, sr, a.chain, a.Cin, c0, goff, loff, a.xb);
       TRC(3 + (c0 / 4) * 4);
       __syncthreads();
       TRC(4 + (c0 / 4) * 4);
@@ -369,7 +380,7 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
       if (tail && cin_main == 0) { load_tail_w(); commit_tail_w(); }     // a single input channel: no main chunk has fetched the packed weights
       if (tail) {
         __syncthreads();
-        stage_store<G>(lds, sr, a.chain, a.Cin, cin_main, goff, loff);     // all four slots: channel Cin-1
+        stage_store<G>(lds, sr, a.chain, a.Cin, cin_main, goff, loff, a.xb);     // all four slots: channel Cin-1
         __syncthreads();
         if (has_next) {
           tile_slots<G>(tid, od_n * G::SD - PD, oh_n * S - 1, ow_n * S - 1, a.D, a.H, a.W, goff, loff);
@@ -438,11 +449,22 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
       const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
       float* __restrict__ yc = dpi_at(ybase, (size_t)(cok ? co : 0) * Vo + vbase, a.yb);
       double s = 0.0, q = 0.0;
-      if (interior) {
+      if (a.yb) {
+        // bf16 destination: two voxels per dword store where the rows are even-aligned (dpi_st_bf16_row); statistics describe what is stored
+        const bool pairs = !(Wo & 1) && !(Vo & 1) && !((uintptr_t)ybase & 3);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const float v = dpi_stored(acc[t][r] + bv, a.yb);        // statistics describe what is stored
-          dpi_st(yc, (t / NH) * Wo + (t % NH) * 16, v, a.yb);
+          const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
+          const bool ok = interior || (cok && od < Do && oh < Ho && ow < Wo);
+          const float v = dpi_round_bf16(acc[t][r] + bv);
+          dpi_st_bf16_row(yc, (t / NH) * Wo + (t % NH) * 16, v, ok, pairs, lj);
+          if (ok) { s += v; q += (double)v * v; }
+        }
+      } else if (interior) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float v = acc[t][r] + bv;
+          yc[(t / NH) * Wo + (t % NH) * 16] = v;
           if (a.partials) { s += v; q += (double)v * v; }
         }
       } else {
@@ -450,8 +472,8 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
         for (int t = 0; t < NT; ++t) {
           const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
           if (cok && od < Do && oh < Ho && ow < Wo) {
-            const float v = dpi_stored(acc[t][r] + bv, a.yb);
-            dpi_st(yc, (t / NH) * Wo + (t % NH) * 16, v, a.yb);
+            const float v = acc[t][r] + bv;
+            yc[(t / NH) * Wo + (t % NH) * 16] = v;
             s += v;
             q += (double)v * v;
           }
@@ -503,7 +525,9 @@ struct BwMArgs {
   // rows — and the chunk's X halo rows — run back to back on ONE XCD and find them in its L2 instead of re-reading HBM
   // (measured before: 3.4 GB fetched per launch for 0.69 GB algorithmic on 25 -> 16).
   int ngroups, nchunks;
-  int xb, dyb;              // storage type of the tensor behind `x` (staged) and behind `dy` (the 16-row operand): 1 = bf16 (roles as AFTER a swap)
+  // storage type of the tensor behind `x` (staged) and behind `dy` (the 16-row operand), roles as AFTER a swap: 0 = fp32, 1 = bf16;
+  // dyb = 2: bf16 whose row pieces are not 4-byte aligned (odd row length or channel size): four 2-byte loads instead of one 8-byte load
+  int xb, dyb;
 };
 
 // TC != 0: the launch covers a final group that holds only TC real channels (Cin = 4m + 1: TC = 1) and computes just their
@@ -598,8 +622,8 @@ __device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a_in, f
     TRW();
     __syncthreads();
     TRW();
-    stage_store<G>(lds, sr, a.chain, a.Cin, c0, goff, loff);
-    if constexpr (NG == 2) stage_store<G>(lds + 4 * G::CS, sr2, a.chain, a.Cin, c0 + 4, goff, loff);
+    stage_store<G>(lds, sr, a.chain, a.Cin, c0, goff, loff, a.xb);
+    if constexpr (NG == 2) stage_store<G>(lds + 4 * G::CS, sr2, a.chain, a.Cin, c0 + 4, goff, loff, a.xb);
     __syncthreads();
     TRW();
     const int cod = od0 + wz, coh0 = oh0 + wh, cow0 = ow0;
@@ -614,10 +638,13 @@ __device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a_in, f
 #pragma unroll
       for (int j = 0; j < JP; ++j) {
         const int p4 = 4 * (wp + 4 * j);
-        if (a.dyb) {        // four bf16 in one 8-byte piece
+        if (a.dyb == 1) {        // four bf16 in one 8-byte piece, kept raw in [0], [1] (put_row widens)
           const dpi_u32x2v u = __builtin_bit_cast(dpi_u32x2v, __builtin_amdgcn_raw_buffer_load_b64(dyb, (row_ok && cow0 + p4 < Wo) ? (base + p4) * 2 : -8, 0, 0));
-          raw[j] = (f32x4){__builtin_bit_cast(float, u[0] << 16), __builtin_bit_cast(float, u[0] & 0xffff0000u),
-                           __builtin_bit_cast(float, u[1] << 16), __builtin_bit_cast(float, u[1] & 0xffff0000u)};
+          const unsigned u0 = u.x, u1 = u.y;     // (hipcc: __builtin_bit_cast of a vector SUBSCRIPT u[1] yields element 0 — copy to scalars first)
+          raw[j] = (f32x4){__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1), 0.f, 0.f};
+        } else if (a.dyb) {      // pieces at odd element offsets: a multi-dword buffer load needs dword alignment; raw 16 bits each
+#pragma unroll
+          for (int e = 0; e < 4; ++e) raw[j][e] = dpi_buffer_load_bf16_raw(dyb, (row_ok && cow0 + p4 < Wo) ? base + p4 + e : -1);
         } else
           raw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyb, (row_ok && cow0 + p4 < Wo) ? (base + p4) * 4 : -16, 0, 0));
       }
@@ -627,6 +654,13 @@ __device__ __forceinline__ void conv_bwd_weight_mfma_body(const BwMArgs& a_in, f
       for (int j = 0; j < JP; ++j) {
         const int p4 = 4 * (wp + 4 * j);
         f32x4 v = raw[j];
+        if (a.dyb == 1) {
+          const float4 wv = dpi_widen_raw4(make_float4(v[0], v[1], 0.f, 0.f));
+          v = (f32x4){wv.x, wv.y, wv.z, wv.w};
+        } else if (a.dyb) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = dpi_widen_raw(v[e]);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = cow0 + p4 + e < Wo ? v[e] : 0.f;   // columns past the row end belong to the next row
         *reinterpret_cast<f32x4*>(dyw + wch * DYRS + p4) = v;
@@ -823,8 +857,13 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_smallco_kernel(BwSArgs a)
 #pragma unroll                                           // Cin re-read the last one (their rows of dW are never written)
     for (int c = 0; c < CB; ++c) {
       const __amdgpu_buffer_rsrc_t r = dpi_buffer_t(dpi_at(a.x, (size_t)min(c0 + c, a.Cin - 1) * V, a.xb), V, a.xb);
+      if (a.xb) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) sr[c][e] = a.xb ? dpi_buffer_load_bf16(r, goff[e]) : dpi_buffer_load(r, goff[e] * 4);
+        for (int e = 0; e < E; ++e) sr[c][e] = dpi_buffer_load_bf16_raw(r, goff[e]);          // raw bits, widened at the LDS store below
+      } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) sr[c][e] = dpi_buffer_load(r, goff[e] * 4);
+      }
     }
   };
   int od0 = 0, oh0 = 0, ow0 = 0;
@@ -836,7 +875,8 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_smallco_kernel(BwSArgs a)
       const Chain t = load_chain(a.chain, min(c0 + c, a.Cin - 1));
 #pragma unroll
       for (int e = 0; e < E; ++e) {
-        const float v = goff[e] >= 0 ? apply_chain(t, sr[c][e]) : sr[c][e];
+        const float xv = a.xb ? dpi_widen_raw(sr[c][e]) : sr[c][e];
+        const float v = goff[e] >= 0 ? apply_chain(t, xv) : xv;
         if ((e + 1) * 256 <= TILE || loff[e] >= 0) lds[c * CS + loff[e]] = v;
       }
     }
@@ -846,14 +886,27 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_smallco_kernel(BwSArgs a)
       const int oh = coh0 + hr;
       const bool ok = wch < a.Cout && cod < a.D && oh < a.H && cow0 + wp4 < a.W;
       const int el = wch * (int)V + (cod * a.H + oh) * a.W + cow0 + wp4;
-      if (a.dyb) {
+      if (a.dyb == 1) {          // raw: put_row widens
         const dpi_u32x2v u = __builtin_bit_cast(dpi_u32x2v, __builtin_amdgcn_raw_buffer_load_b64(dyb, ok ? el * 2 : -8, 0, 0));
-        return (f32x4){__builtin_bit_cast(float, u[0] << 16), __builtin_bit_cast(float, u[0] & 0xffff0000u),
-                       __builtin_bit_cast(float, u[1] << 16), __builtin_bit_cast(float, u[1] & 0xffff0000u)};
+        const unsigned u0 = u.x, u1 = u.y;
+        return (f32x4){__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1), 0.f, 0.f};
+      }
+      if (a.dyb) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dpi_buffer_load_bf16_raw(dyb, ok ? el + e : -1);
+        return v;
       }
       return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyb, ok ? el * 4 : -16, 0, 0));
     };
     auto put_row = [&](f32x4 v) {
+      if (a.dyb == 1) {
+        const float4 wv = dpi_widen_raw4(make_float4(v[0], v[1], 0.f, 0.f));
+        v = (f32x4){wv.x, wv.y, wv.z, wv.w};
+      } else if (a.dyb) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dpi_widen_raw(v[e]);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = cow0 + wp4 + e < a.W ? v[e] : 0.f;
       if (wch < 5) *reinterpret_cast<f32x4*>(dyw + wch * DYRS + 4 + wp4) = v;
@@ -972,8 +1025,13 @@ __global__ __launch_bounds__(256) void conv_bwd_data_s2_mfma_kernel(BdS2Args a) 
     for (int c = 0; c < 4; ++c) {
       // channels past Cout re-read the last one: their weights are zero
       const __amdgpu_buffer_rsrc_t r = dpi_buffer_t(dpi_at(a.dy, (size_t)min(c0 + c, a.Cout - 1) * Vo, a.dyb), Vo, a.dyb);
+      if (a.dyb) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) sr[c][e] = a.dyb ? dpi_buffer_load_bf16(r, goff[e]) : dpi_buffer_load(r, goff[e] * 4);      // outside the tile / volume -> 0
+        for (int e = 0; e < E; ++e) sr[c][e] = dpi_buffer_load_bf16_raw(r, goff[e]);       // raw bits, widened at the LDS store
+      } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) sr[c][e] = dpi_buffer_load(r, goff[e] * 4);          // outside the tile / volume -> 0
+      }
     }
   };
   fetch(0);
@@ -989,7 +1047,7 @@ __global__ __launch_bounds__(256) void conv_bwd_data_s2_mfma_kernel(BdS2Args a) 
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int e = 0; e < E; ++e)
-        if ((e + 1) * 256 <= TILE || loff[e] >= 0) lds[c * CS + loff[e]] = sr[c][e];
+        if ((e + 1) * 256 <= TILE || loff[e] >= 0) lds[c * CS + loff[e]] = a.dyb ? dpi_widen_raw(sr[c][e]) : sr[c][e];
     __syncthreads();
     if (c0 + 4 < a.Cout) fetch(c0 + 4);
     // every (shift_d, shift_h, shift_w, row) sample of the tile feeds the classes whose parity allows that shift
@@ -1282,6 +1340,11 @@ size_t dpi_conv_bwd_weight_mfma_ws_floats(const dpi_conv_desc* d) {
 }
 bool dpi_conv_bwd_weight_mfma_swapped(const dpi_conv_desc* d, const float* chain) { return chain == nullptr && mfma_bw_swap_better(d); }
 
+// dyb class of a bf16 row operand: 1 when every 4-element piece starts 4-byte aligned (even row length and channel size, aligned base)
+static int bf16_row_class(const void* base, int row_len, size_t channel_elems) {
+  return ((row_len & 1) == 0 && (channel_elems & 1) == 0 && ((uintptr_t)base & 3) == 0) ? 1 : 2;
+}
+
 int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws,
                                  hipStream_t st) {
   const bool swap = dpi_conv_bwd_weight_mfma_swapped(d, chain);     // the chain can only be applied to the staged tensor
@@ -1293,6 +1356,11 @@ int dpi_conv_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, const f
     a.x = dy; a.chain = nullptr; a.dy = x; a.Cin = d->Cout; a.Cout = d->Cin; a.swap = 1;
     a.xb = (d->io & DPI_IO_DY_BF16) != 0; a.dyb = (d->io & DPI_IO_X_BF16) != 0;
     grid = dim3(p.nchunks, cdiv(d->Cout, 4), cdiv(d->Cin, 16));
+  }
+  if (a.dyb) {        // the 16-row operand is read in 4-element pieces of its rows (output-sized without a swap, input-sized — stride 1 — with it)
+    int Do_, Ho_, Wo_;
+    dpi_conv_out_dims(d, &Do_, &Ho_, &Wo_);
+    a.dyb = swap ? bf16_row_class(a.dy, d->W, (size_t)d->D * d->H * d->W) : bf16_row_class(a.dy, Wo_, (size_t)Do_ * Ho_ * Wo_);
   }
   // (chunk, group) grid -> 1-D XCD-aware order (see BwMArgs::ngroups)
   auto xcd_grid = [&](dim3 g) {
@@ -1393,7 +1461,7 @@ int dpi_conv_bwd_weight_smallco_run(const dpi_conv_desc* d, const float* x, cons
                                     hipStream_t st) {
   const SmallBwPlan p = small_bw_plan(d);
   BwSArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.ntd, p.nth, p.ntw, p.ntiles, p.tiles_per_chunk,
-            (d->io & DPI_IO_X_BF16) != 0, (d->io & DPI_IO_DY_BF16) != 0};
+            (d->io & DPI_IO_X_BF16) != 0, (d->io & DPI_IO_DY_BF16) ? bf16_row_class(dy, d->W, (size_t)d->D * d->H * d->W) : 0};
   conv_bwd_weight_smallco_kernel<<<dim3(p.nchunks, cdiv(d->Cin, 6)), 256, 0, st>>>(a);
   if (int e = dpi_check_launch("conv_bwd_weight_smallco")) return e;
   const size_t per = (size_t)d->Cout * d->Cin * 27;

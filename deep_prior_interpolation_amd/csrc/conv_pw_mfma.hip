@@ -11,6 +11,7 @@
 //              lane loads float4 dy[co = lj][v0 + 4*lk .. +3] and x[ci = lj][v0 + 4*lk .. +3]; element e pairs the voxels
 //              {v0 + 4*lk + e} of both operands.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -36,8 +37,11 @@ struct PwMArgs {
 // conflict-free ds_read_b32), so the streaming loop's only global loads are the activations.
 constexpr int kPwLdsFloats = 12288;     // 48 KiB
 
-template <int MT, bool WLDS>
+// IOB: the launch touches a bf16 tensor (PwMArgs::xb / yb).  A template parameter, as in conv_mfma.hip: the run-time flags alone cost the
+// fp32 instantiations 10 % (forward) to 3.8 x (backward-weight: every row's loads landed in a branch of their own and serialised).
+template <int MT, bool WLDS, bool IOB = false>
 __global__ __launch_bounds__(256) void conv_pw_mfma_kernel(PwMArgs a) {
+  if constexpr (!IOB) { a.xb = 0; a.yb = 0; }
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lk = lane >> 4, lj = lane & 15;
   const int n0 = blockIdx.y * 16 * MT;
@@ -74,16 +78,30 @@ __global__ __launch_bounds__(256) void conv_pw_mfma_kernel(PwMArgs a) {
     const bool full4 = vec && v0 + 3 < a.V;
     for (int cb = 0; cb < nchunk; cb += PF) {
       float b[PF][4];
+      if (a.xb && full4) {      // bf16 tensor: the batch's 8-byte pieces are all requested (raw) before any is widened — one uniform branch (common.h)
+        float4 h[PF];
 #pragma unroll
-      for (int p = 0; p < PF; ++p) {
-        const int ci = min((cb + p) * 4 + lk, a.Cin - 1);       // past Cin: re-read the last channel, weights are zero
-        const float* __restrict__ xp = dpi_at(a.x, (size_t)ci * a.V, a.xb);
-        if (full4) {
-          const float4 f = dpi_ld4(xp, v0, a.xb, false);
+        for (int p = 0; p < PF; ++p) {
+          const int ci = min((cb + p) * 4 + lk, a.Cin - 1);
+          h[p] = dpi_ld4_raw_bf16(dpi_at(a.x, (size_t)ci * a.V, true), v0);
+        }
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+          const float4 f = dpi_widen_raw4(h[p]);
           b[p][0] = f.x; b[p][1] = f.y; b[p][2] = f.z; b[p][3] = f.w;
-        } else {
+        }
+      } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const float v = dpi_ld(xp, v0 + e < a.V ? v0 + e : 0, a.xb); b[p][e] = v0 + e < a.V ? v : 0.f; }
+        for (int p = 0; p < PF; ++p) {
+          const int ci = min((cb + p) * 4 + lk, a.Cin - 1);       // past Cin: re-read the last channel, weights are zero
+          const float* __restrict__ xp = dpi_at(a.x, (size_t)ci * a.V, a.xb);
+          if (full4) {
+            const float4 f = *reinterpret_cast<const float4*>(xp + v0);
+            b[p][0] = f.x; b[p][1] = f.y; b[p][2] = f.z; b[p][3] = f.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float v = dpi_ld(xp, v0 + e < a.V ? v0 + e : 0, a.xb); b[p][e] = v0 + e < a.V ? v : 0.f; }
+          }
         }
       }
 #pragma unroll
@@ -180,8 +198,12 @@ struct PwBwArgs {
   int xb, dyb;              // storage type of x / dy: 1 = bf16
 };
 
-template <int MT, int NT>   // MT cout tiles x NT cin tiles per block
+// XB / DYB: storage type of x / dy (bf16 = true) as TEMPLATE parameters.  As run-time flags every row's loads sat in a branch of their own
+// whose results had to be copied into the common registers at the branch's end — i.e. waited for — and the six rows of a round loaded one
+// after the other (67->25 @256x128x128: 0.41 -> 1.99 ms with HALF the bytes).
+template <int MT, int NT, bool XB = false, bool DYB = false>   // MT cout tiles x NT cin tiles per block
 __global__ __launch_bounds__(256) void conv_pw_bwd_weight_mfma_kernel(PwBwArgs a) {
+  a.xb = XB; a.dyb = DYB;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lk = lane >> 4, lj = lane & 15;
   const int ci0 = blockIdx.y * 16 * NT, co0 = blockIdx.z * 16 * MT;
@@ -213,12 +235,29 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_weight_mfma_kernel(PwBwArgs a
     const size_t v0 = g0 + 4 * lk;
     auto vox = [&](int e) { return v0 + 16 * (e >> 2) + (e & 3); };
     const bool whole = vec && g0 + 63 < vend;
-    float ga[MT][16], xb[NT][16];
-    auto load16 = [&](const float* __restrict__ p, float (&o)[16], bool bf) {
-      if (whole) {
+    float ga[DYB ? 1 : MT][16], xb[XB ? 1 : NT][16];       // fp32 rows: the 16 values; bf16 rows live in gr / xq (raw) only
+    // bf16 rows: the raw 8-byte pieces wait in their own registers (gr / xq) and are widened into ga / xb once every row of the round has
+    // been requested.  (Widening in place — raw dwords in o[4j], o[4j + 1], values written over them — sent the arrays to scratch: 400 bytes
+    // per lane, 67->25 1.94 ms.)
+    float gr[DYB ? MT : 1][8], xq[XB ? NT : 1][8];
+    auto load16 = [&](const float* __restrict__ p, float (&o)[16], float (&rw)[8], bool bf) {
+      if (whole && bf) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float4 f = dpi_ld4(p, v0 + 16 * j, bf, false);
+          const float4 f = dpi_ld4_raw_bf16(p, v0 + 16 * j);
+          rw[2 * j] = f.x; rw[2 * j + 1] = f.y;
+        }
+      } else if (bf) {         // ragged round of a bf16 row: the same raw layout (two elements per dword), element by element
+        const unsigned short* __restrict__ ph = reinterpret_cast<const unsigned short*>(p);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const unsigned lo = vox(2 * k) < vend ? ph[vox(2 * k)] : 0u, hi = vox(2 * k + 1) < vend ? ph[vox(2 * k + 1)] : 0u;
+          rw[k] = __builtin_bit_cast(float, lo | (hi << 16));
+        }
+      } else if (whole) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 f = *reinterpret_cast<const float4*>(p + v0 + 16 * j);
           o[4 * j] = f.x; o[4 * j + 1] = f.y; o[4 * j + 2] = f.z; o[4 * j + 3] = f.w;
         }
       } else {
@@ -230,10 +269,54 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_weight_mfma_kernel(PwBwArgs a
     // are skipped — block-uniform tests; without them those tiles re-read the clamped last channel 16 times over
 #pragma unroll
     for (int m = 0; m < MT; ++m)
-      if (m < mt_valid) load16(dyr[m], ga[m], a.dyb);
+      if (m < mt_valid) load16(dyr[m], ga[DYB ? 0 : m], gr[DYB ? m : 0], DYB);
 #pragma unroll
     for (int n = 0; n < NT; ++n)
-      if (n < nt_valid) load16(xr[n], xb[n], a.xb);
+      if (n < nt_valid) load16(xr[n], xb[XB ? 0 : n], xq[XB ? n : 0], XB);
+    if constexpr (XB || DYB) {
+      // bf16 rows are widened piece by piece right before their MFMAs (raw 8 registers per row + 4 live values instead of 16 per row);
+      // the MFMA order per accumulator is the fp32 kernel's (e ascending), so both instantiations give bit-identical sums
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float gv[MT][4], xv[NT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          if (m < mt_valid) {
+            if (DYB) {
+              const float4 f = dpi_widen_raw4(make_float4(gr[DYB ? m : 0][2 * j], gr[DYB ? m : 0][2 * j + 1], 0.f, 0.f));
+              gv[m][0] = f.x; gv[m][1] = f.y; gv[m][2] = f.z; gv[m][3] = f.w;
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) gv[m][i] = ga[DYB ? 0 : m][4 * j + i];
+            }
+          }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          if (n < nt_valid) {
+            if (XB) {
+              const float4 f = dpi_widen_raw4(make_float4(xq[XB ? n : 0][2 * j], xq[XB ? n : 0][2 * j + 1], 0.f, 0.f));
+              xv[n][0] = f.x; xv[n][1] = f.y; xv[n][2] = f.z; xv[n][3] = f.w;
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) xv[n][i] = xb[XB ? 0 : n][4 * j + i];
+            }
+            if (a.chain) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) xv[n][i] = (vox(4 * j + i) < vend) ? apply_chain(ch[n], xv[n][i]) : 0.f;
+            }
+          }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          if (m < mt_valid) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              if (n < nt_valid) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[m][i], xv[n][i], acc[m][n], 0, 0, 0);
+              }
+          }
+      }
+    } else {
     if (a.chain) {
 #pragma unroll
       for (int n = 0; n < NT; ++n)
@@ -252,6 +335,7 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_weight_mfma_kernel(PwBwArgs a
             for (int e = 0; e < 16; ++e) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[m][e], xb[n][e], acc[m][n], 0, 0, 0);
           }
       }
+    }
   }
   // cross-wave reduction; D row = co (4*lk + r), col = ci lj
   __shared__ float red[4][MT * NT * 4 * 64];
@@ -332,6 +416,12 @@ int dpi_conv_pw_mfma_run(const dpi_conv_desc* d, const float* x, const float* ch
   // the weight tile is the kernel's only sizeable LDS: allocated to size (8-9 KB for the full-resolution layers), so that registers
   // and not a fixed 48 KB bound the number of resident workgroups (= loads in flight per CU of an HBM-bound kernel)
   const size_t wbytes = wlds ? (size_t)cdiv(cin, 4) * mt * 64 * sizeof(float) : 0;
+  if (a.xb || a.yb) {
+    if (mt == 1) { if (wlds) conv_pw_mfma_kernel<1, true, true><<<grid, 256, wbytes, st>>>(a); else conv_pw_mfma_kernel<1, false, true><<<grid, 256, 0, st>>>(a); }
+    else if (mt == 2) { if (wlds) conv_pw_mfma_kernel<2, true, true><<<grid, 256, wbytes, st>>>(a); else conv_pw_mfma_kernel<2, false, true><<<grid, 256, 0, st>>>(a); }
+    else { if (wlds) conv_pw_mfma_kernel<4, true, true><<<grid, 256, wbytes, st>>>(a); else conv_pw_mfma_kernel<4, false, true><<<grid, 256, 0, st>>>(a); }
+    return dpi_check_launch("conv_pw_mfma");
+  }
   if (mt == 1) { if (wlds) conv_pw_mfma_kernel<1, true><<<grid, 256, wbytes, st>>>(a); else conv_pw_mfma_kernel<1, false><<<grid, 256, 0, st>>>(a); }
   else if (mt == 2) { if (wlds) conv_pw_mfma_kernel<2, true><<<grid, 256, wbytes, st>>>(a); else conv_pw_mfma_kernel<2, false><<<grid, 256, 0, st>>>(a); }
   else { if (wlds) conv_pw_mfma_kernel<4, true><<<grid, 256, wbytes, st>>>(a); else conv_pw_mfma_kernel<4, false><<<grid, 256, 0, st>>>(a); }
@@ -348,15 +438,22 @@ int dpi_conv_pw_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, cons
   const PwBwPlan p = pw_bw_plan(d);
   PwBwArgs a{x, chain, dy, ws, d->Cin, d->Cout, (size_t)d->D * d->H * d->W, p.vox_per_chunk, (d->io & DPI_IO_X_BF16) != 0, (d->io & DPI_IO_DY_BF16) != 0};
   dim3 grid(p.nchunks, cdiv(d->Cin, 16 * p.nt), cdiv(d->Cout, 16 * p.mt));
-  if (p.mt == 1) {
-    if (p.nt == 1) conv_pw_bwd_weight_mfma_kernel<1, 1><<<grid, 256, 0, st>>>(a);
-    else if (p.nt == 2) conv_pw_bwd_weight_mfma_kernel<1, 2><<<grid, 256, 0, st>>>(a);
-    else conv_pw_bwd_weight_mfma_kernel<1, 4><<<grid, 256, 0, st>>>(a);
-  } else {
-    if (p.nt == 1) conv_pw_bwd_weight_mfma_kernel<2, 1><<<grid, 256, 0, st>>>(a);
-    else if (p.nt == 2) conv_pw_bwd_weight_mfma_kernel<2, 2><<<grid, 256, 0, st>>>(a);
-    else conv_pw_bwd_weight_mfma_kernel<2, 4><<<grid, 256, 0, st>>>(a);
-  }
+  auto launch = [&](auto xb_, auto dyb_) {
+    constexpr bool XB = decltype(xb_)::value, DYB = decltype(dyb_)::value;
+    if (p.mt == 1) {
+      if (p.nt == 1) conv_pw_bwd_weight_mfma_kernel<1, 1, XB, DYB><<<grid, 256, 0, st>>>(a);
+      else if (p.nt == 2) conv_pw_bwd_weight_mfma_kernel<1, 2, XB, DYB><<<grid, 256, 0, st>>>(a);
+      else conv_pw_bwd_weight_mfma_kernel<1, 4, XB, DYB><<<grid, 256, 0, st>>>(a);
+    } else {
+      if (p.nt == 1) conv_pw_bwd_weight_mfma_kernel<2, 1, XB, DYB><<<grid, 256, 0, st>>>(a);
+      else if (p.nt == 2) conv_pw_bwd_weight_mfma_kernel<2, 2, XB, DYB><<<grid, 256, 0, st>>>(a);
+      else conv_pw_bwd_weight_mfma_kernel<2, 4, XB, DYB><<<grid, 256, 0, st>>>(a);
+    }
+  };
+  if (a.xb && a.dyb) launch(std::true_type{}, std::true_type{});
+  else if (a.xb) launch(std::true_type{}, std::false_type{});
+  else if (a.dyb) launch(std::false_type{}, std::true_type{});
+  else launch(std::false_type{}, std::false_type{});
   if (int e = dpi_check_launch("conv_pw_bwd_weight_mfma")) return e;
   const size_t per = (size_t)d->Cout * d->Cin;
   dpi_reduce_chunks(ws, dw, per, p.nchunks, st);

@@ -30,8 +30,11 @@ __device__ __forceinline__ void st4(float* p, float4 v, bool nt) {
 }
 
 // ---- per-channel {sum, sum^2} of T(x) ------------------------------------------------------------------
+// (storage types are TEMPLATE parameters in this file: with a run-time flag every load sits in its own `if (bf16)` and, because the bf16
+//  side widens what it loads, waits for its data inside that branch — the two or three streams of a pass then load one after the other)
+template <bool xb = false>
 __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, const float* __restrict__ chain,
-                                                            int C, size_t V, int nblk, double* __restrict__ partials, bool xb = false) {
+                                                            int C, size_t V, int nblk, double* __restrict__ partials) {
   const bool nt = (size_t)gridDim.y * V >= kNtMinFloats;
   const int c = blockIdx.y, b = blockIdx.x;
   const size_t span = stat_span(V, nblk);
@@ -122,8 +125,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   }
 }
 
+template <bool xb = false, bool yb = false>
 __global__ __launch_bounds__(256) void chain_apply_kernel(const float* __restrict__ x, const float* __restrict__ chain, size_t V,
-                                                          float* __restrict__ y, bool xb = false, bool yb = false) {
+                                                          float* __restrict__ y) {
   const bool nt = (size_t)gridDim.y * V >= kNtMinFloats;
   const int c = blockIdx.y;
   const Chain t = load_chain(chain, c);
@@ -172,11 +176,12 @@ __device__ __forceinline__ void bn_bwd_elem(const BnBwd& k, float x, float dy, f
   g = (k.post == 1.f || yv > 0.f) ? dy : dy * k.post;
 }
 
+template <bool fb = false, bool gb = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ in_chain,
                                                             float pre, float post, int C, size_t V, int nblk,
-                                                            double* __restrict__ partials, bool fb = false, bool gb = false) {
+                                                            double* __restrict__ partials) {
   // fb: the forward tensor x is bf16; gb: the gradient tensor dy is bf16 (all BatchNorm-backward kernels below alike)
   const bool nt = (size_t)gridDim.y * V >= kNtMinFloats;
   const int c = blockIdx.y, b = blockIdx.x;
@@ -217,12 +222,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
+template <bool fb = false, bool gb = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ in_chain,
                                                            float pre, float post, const double* __restrict__ partials, int nblk, int C, size_t V,
                                                            float* __restrict__ dx, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, bool fb = false, bool gb = false) {
+                                                           float* __restrict__ dbeta) {
   const bool nt = (size_t)gridDim.y * V >= kNtMinFloats;
   const int c = blockIdx.y;
   __shared__ double tot[2];
@@ -265,10 +271,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 // ---- t = T_a(a) + T_b(b), and {sum, sum^2} of act(t): the residual join of Block3d / ResPath3d in one pass -----------
+template <bool fb = false>
 __global__ __launch_bounds__(256) void chain_add_stats_kernel(const float* __restrict__ a, const float* __restrict__ chain_a,
                                                               const float* __restrict__ b, const float* __restrict__ chain_b, int C,
                                                               size_t V, int nblk, float slope, float* __restrict__ t,
-                                                              double* __restrict__ partials, bool fb = false) {
+                                                              double* __restrict__ partials) {
   const bool nt = (size_t)gridDim.y * V >= kNtMinFloats;
   const int c = blockIdx.y, blk = blockIdx.x;
   const size_t span = stat_span(V, nblk);
@@ -328,13 +335,13 @@ struct BnFork {
   float post;
   double* partials;          // [nblk][C][2]
 };
+template <bool tb = false, bool gb = false>       // tb: forward tensors (x, fa.x, fb.x) bf16; gb: dy, dx bf16
 __global__ __launch_bounds__(256) void bn_bwd_apply_fork_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, const float* __restrict__ in_chain,
                                                                 float pre, float post, const double* __restrict__ partials, int nblk_in,
                                                                 int C, size_t V, int nblk, float* __restrict__ dx,
-                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, BnFork fa, BnFork fb,
-                                                                bool tb = false, bool gb = false) {      // tb: forward tensors (x, fa.x, fb.x) bf16; gb: dy, dx bf16
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, BnFork fa, BnFork fb) {
   const bool nt = (size_t)gridDim.y * V >= kNtMinFloats;
   const int c = blockIdx.y, b = blockIdx.x;
   __shared__ double tot[2];
@@ -424,10 +431,11 @@ struct BnSide {
   float* dgamma;
   float* dbeta;
 };
+template <bool tb = false, bool gb = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_dual_kernel(const float* __restrict__ dy, BnSide A, BnSide B, int nblk_in, int C, size_t V,
                                                                 int nblk, int f_lo, int f_hi, const float* __restrict__ f_mi,
                                                                 const float* __restrict__ f_gamma, const float* __restrict__ f_beta,
-                                                                float f_post, double* __restrict__ f_partials, bool tb = false, bool gb = false) {
+                                                                float f_post, double* __restrict__ f_partials) {
   const bool nt = (size_t)gridDim.y * V >= kNtMinFloats;
   const int c = blockIdx.y, b = blockIdx.x;
   __shared__ double tot[4];
@@ -597,9 +605,10 @@ __device__ __forceinline__ void lin_src(int o, int n, int& i0, int& i1, float& w
   else { i0 = max(h - 1, 0); i1 = h; w0 = (h == 0) ? 0.f : .25f; w1 = (h == 0) ? 1.f : .75f; }
 }
 
+template <bool xb = false, bool yb = false>
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, const float* __restrict__ chain, int D, int H,
                                                            int W, int Do, int Ho, int Wo, int linear, int scale_d,
-                                                           float* __restrict__ y, bool xb = false, bool yb = false) {
+                                                           float* __restrict__ y) {
   const int c = blockIdx.y;
   const size_t Vo = (size_t)Do * Ho * Wo, V = (size_t)D * H * W;
   const Chain t = load_chain(chain, c);
@@ -634,8 +643,9 @@ __device__ __forceinline__ float lin_wt(int o, int i, int n) {
   return (i0 == i ? w0 : 0.f) + (i1 == i ? w1 : 0.f);
 }
 
+template <bool gb = false>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, int D, int H, int W, int Do, int Ho, int Wo,
-                                                           int linear, int scale_d, float* __restrict__ dx, bool gb = false) {
+                                                           int linear, int scale_d, float* __restrict__ dx) {
   const int c = blockIdx.y;
   const size_t Vo = (size_t)Do * Ho * Wo, V = (size_t)D * H * W;
   const float* __restrict__ gc = dpi_at(dy, (size_t)c * Vo, gb);
@@ -670,10 +680,9 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
 // ---- x2 linear up-sampling, fast 3-D / 2-D paths ------------------------------------------------------------------------
 // forward: one thread per INPUT voxel produces its 2x2x2 output cube from the 3x3x3 (edge-clamped) neighbourhood:
 //   out[2i] = .25 in[i-1] + .75 in[i],  out[2i+1] = .75 in[i] + .25 in[i+1]   per axis (27 loads for 8 outputs)
-template <bool SCALE_D>
+template <bool SCALE_D, bool xb = false, bool yb = false>
 __global__ __launch_bounds__(256) void upsample_lin_fwd_cube_kernel(const float* __restrict__ x, const float* __restrict__ chain, int D, int H,
-                                                                    int W, int Do, int Ho, int Wo, float* __restrict__ y, bool xb = false,
-                                                                    bool yb = false) {
+                                                                    int W, int Do, int Ho, int Wo, float* __restrict__ y) {
   const int c = blockIdx.y;
   const size_t V = (size_t)D * H * W, Vo = (size_t)Do * Ho * Wo;
   const Chain t = load_chain(chain, c);
@@ -743,9 +752,9 @@ __device__ __forceinline__ void lin_bwd_taps(int i, int n, int no, int (&o)[4], 
   }
 }
 
-template <bool SCALE_D>
+template <bool SCALE_D, bool gb = false>
 __global__ __launch_bounds__(256) void upsample_lin_bwd_gather_kernel(const float* __restrict__ dy, int D, int H, int W, int Do, int Ho,
-                                                                      int Wo, float* __restrict__ dx, bool gb = false) {
+                                                                      int Wo, float* __restrict__ dx) {
   const int c = blockIdx.y;
   const size_t V = (size_t)D * H * W, Vo = (size_t)Do * Ho * Wo;
   const float* __restrict__ gc = dpi_at(dy, (size_t)c * Vo, gb);
@@ -780,8 +789,9 @@ __global__ __launch_bounds__(256) void upsample_lin_bwd_gather_kernel(const floa
 //   out[i] = .25 in[2i-1] + .75 in[2i] + .75 in[2i+1] + .25 in[2i+2]   (edge weights 1 at i = 0 / n-1, taps >= no dropped).
 // Three coalesced passes (W, H, D) move 2.6x the gradient once instead of gathering 64 strided values per voxel
 // (8 L1 requests per voxel): 0.95 -> ~0.5 ms for the 51-channel full-resolution tensor.
+template <bool ib = false, bool ob = false>
 __global__ __launch_bounds__(256) void upsample_lin_bwd_axis_kernel(const float* __restrict__ in, float* __restrict__ out, unsigned outer,
-                                                                    int n, int no, unsigned inner, bool ib = false, bool ob = false) {
+                                                                    int n, int no, unsigned inner) {
   // blockIdx.x walks one [n][inner] slab (32-bit index math only), blockIdx.y strides over the outer slabs; a slab shorter
   // than the workgroup (the W pass: one row) shares it with its neighbours
   const unsigned slab = (unsigned)n * inner;
@@ -858,6 +868,17 @@ extern "C" int dpi_stat_blocks(int C, size_t V) {
   return (int)n;
 }
 
+// launch KERNEL<forward tensors bf16, gradient tensors bf16> for the two bits of an `io` mask
+#define DPI_LAUNCH_FG(io, KERNEL, GRID, ST, ...)                                          \
+  do {                                                                                    \
+    if (DPI_FB(io)) {                                                                     \
+      if (DPI_GB(io)) KERNEL<true, true><<<GRID, 256, 0, ST>>>(__VA_ARGS__);              \
+      else KERNEL<true, false><<<GRID, 256, 0, ST>>>(__VA_ARGS__);                        \
+    } else {                                                                              \
+      if (DPI_GB(io)) KERNEL<false, true><<<GRID, 256, 0, ST>>>(__VA_ARGS__);             \
+      else KERNEL<false, false><<<GRID, 256, 0, ST>>>(__VA_ARGS__);                       \
+    }                                                                                     \
+  } while (0)
 #define DPI_FB(io) (((io) & DPI_STORE_FWD_BF16) != 0)
 #define DPI_GB(io) (((io) & DPI_STORE_GRAD_BF16) != 0)
 #define DPI_REQUIRE_IO(io, what) DPI_REQUIRE(((io) & ~3u) == 0, what ": unknown storage-type bits in io = %u", (unsigned)(io))
@@ -866,7 +887,8 @@ extern "C" int dpi_channel_stats_io(const float* x, const float* chain, int C, s
   DPI_REQUIRE(x && partials && C > 0 && V > 0, "channel_stats: bad argument");
   DPI_REQUIRE_IO(io, "channel_stats");
   const int nblk = dpi_stat_blocks(C, V);
-  channel_stats_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(x, chain, C, V, nblk, partials, DPI_FB(io));
+  if (DPI_FB(io)) channel_stats_kernel<true><<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(x, chain, C, V, nblk, partials);
+  else channel_stats_kernel<false><<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(x, chain, C, V, nblk, partials);
   return dpi_check_launch("channel_stats");
 }
 extern "C" int dpi_channel_stats(const float* x, const float* chain, int C, size_t V, double* partials, void* stream) {
@@ -887,7 +909,8 @@ extern "C" int dpi_bn_finalize(const double* partials, int nblk, int C, size_t c
 extern "C" int dpi_chain_apply_io(const float* x, const float* chain, int C, size_t V, float* y, unsigned io, void* stream) {
   DPI_REQUIRE(x && y && C > 0 && V > 0, "chain_apply: bad argument");
   DPI_REQUIRE_IO(io, "chain_apply");
-  chain_apply_kernel<<<dim3(ew_blocks(cdivz(V, 4)), C), 256, 0, (hipStream_t)stream>>>(x, chain, V, y, DPI_FB(io), DPI_FB(io));
+  if (DPI_FB(io)) chain_apply_kernel<true, true><<<dim3(ew_blocks(cdivz(V, 4)), C), 256, 0, (hipStream_t)stream>>>(x, chain, V, y);
+  else chain_apply_kernel<false, false><<<dim3(ew_blocks(cdivz(V, 4)), C), 256, 0, (hipStream_t)stream>>>(x, chain, V, y);
   return dpi_check_launch("chain_apply");
 }
 extern "C" int dpi_chain_apply(const float* x, const float* chain, int C, size_t V, float* y, void* stream) {
@@ -906,8 +929,8 @@ extern "C" int dpi_bn_bwd_reduce_io(const float* dy, const float* x, const float
   DPI_REQUIRE_IO(io, "bn_bwd_reduce");
   DPI_REQUIRE(!in_chain || pre_slope == 1.f, "bn_bwd_reduce: in_chain excludes pre_slope");
   const int nblk = dpi_stat_blocks(C, V);
-  bn_bwd_reduce_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, beta, in_chain, pre_slope, post_slope, C, V,
-                                                                       nblk, partials, DPI_FB(io), DPI_GB(io));
+  DPI_LAUNCH_FG(io, bn_bwd_reduce_kernel, dim3(nblk, C), (hipStream_t)stream, dy, x, mean_invstd, gamma, beta, in_chain, pre_slope, post_slope, C, V,
+                nblk, partials);
   return dpi_check_launch("bn_bwd_reduce");
 }
 
@@ -925,9 +948,8 @@ extern "C" int dpi_bn_bwd_apply_io(const float* dy, const float* x, const float*
   // every workgroup first re-reduces the phase-1 partials of its channel (nblk double pairs): keep >= 8 float4 per thread
   // behind that prologue instead of one
   unsigned gx = ew_blocks(cdivz(V, 4 * 8));
-  bn_bwd_apply_kernel<<<dim3(gx, C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, beta, in_chain, pre_slope,
-                                                                                      post_slope, partials, nblk, C, V, dx, dgamma,
-                                                                                      dbeta, DPI_FB(io), DPI_GB(io));
+  DPI_LAUNCH_FG(io, bn_bwd_apply_kernel, dim3(gx, C), (hipStream_t)stream, dy, x, mean_invstd, gamma, beta, in_chain, pre_slope, post_slope, partials, nblk,
+                C, V, dx, dgamma, dbeta);
   return dpi_check_launch("bn_bwd_apply");
 }
 
@@ -953,8 +975,8 @@ extern "C" int dpi_bn_bwd_apply_fork_io(const float* dy, const float* x, const f
   DPI_REQUIRE((!xa || (mi_a && partials_a)) && (!xb || (mi_b && partials_b)), "bn_bwd_apply_fork: incomplete follow-up BatchNorm");
   const int nb = dpi_stat_blocks(C, V);
   const BnFork fa{xa, mi_a, gamma_a, beta_a, chain_a, post_a, partials_a}, fb{xb, mi_b, gamma_b, beta_b, chain_b, post_b, partials_b};
-  bn_bwd_apply_fork_kernel<<<dim3(nb, C), 256, 0, (hipStream_t)stream>>>(dy, x, mean_invstd, gamma, beta, in_chain, pre_slope, post_slope,
-                                                                        partials, nblk, C, V, nb, dx, dgamma, dbeta, fa, fb, DPI_FB(io), DPI_GB(io));
+  DPI_LAUNCH_FG(io, bn_bwd_apply_fork_kernel, dim3(nb, C), (hipStream_t)stream, dy, x, mean_invstd, gamma, beta, in_chain, pre_slope, post_slope,
+                partials, nblk, C, V, nb, dx, dgamma, dbeta, fa, fb);
   return dpi_check_launch("bn_bwd_apply_fork");
 }
 
@@ -981,8 +1003,8 @@ extern "C" int dpi_bn_bwd_apply_dual_io(const float* dy, int nblk, int C, size_t
   const int nb = dpi_stat_blocks(C, V);
   const BnSide A{xa, mi_a, gamma_a, beta_a, chain_a, post_a, partials_a, dxa, dgamma_a, dbeta_a};
   const BnSide B{xb, mi_b, gamma_b, beta_b, chain_b, post_b, partials_b, dxb, dgamma_b, dbeta_b};
-  bn_bwd_apply_dual_kernel<<<dim3(nb, C), 256, 0, (hipStream_t)stream>>>(dy, A, B, nblk, C, V, nb, f_lo, f_hi, f_mi, f_gamma, f_beta, f_post,
-                                                                        f_partials, DPI_FB(io), DPI_GB(io));
+  DPI_LAUNCH_FG(io, bn_bwd_apply_dual_kernel, dim3(nb, C), (hipStream_t)stream, dy, A, B, nblk, C, V, nb, f_lo, f_hi, f_mi, f_gamma, f_beta, f_post,
+                f_partials);
   return dpi_check_launch("bn_bwd_apply_dual");
 }
 
@@ -995,7 +1017,8 @@ extern "C" int dpi_chain_add_stats_io(const float* a, const float* chain_a, cons
   DPI_REQUIRE(a && b && t && partials && C > 0 && V > 0, "chain_add_stats: bad argument");
   DPI_REQUIRE_IO(io, "chain_add_stats");
   const int nblk = dpi_stat_blocks(C, V);
-  chain_add_stats_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(a, chain_a, b, chain_b, C, V, nblk, slope, t, partials, DPI_FB(io));
+  if (DPI_FB(io)) chain_add_stats_kernel<true><<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(a, chain_a, b, chain_b, C, V, nblk, slope, t, partials);
+  else chain_add_stats_kernel<false><<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(a, chain_a, b, chain_b, C, V, nblk, slope, t, partials);
   return dpi_check_launch("chain_add_stats");
 }
 
@@ -1026,7 +1049,7 @@ extern "C" int dpi_add(const float* a, const float* b, size_t n, float* y, void*
 extern "C" int dpi_channel_sum(const float* x, int C, size_t V, double* ws, float* out, void* stream) {
   DPI_REQUIRE(x && ws && out && C > 0 && V > 0, "channel_sum: bad argument");
   const int nblk = dpi_stat_blocks(C, V);
-  channel_stats_kernel<<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(x, nullptr, C, V, nblk, ws);
+  channel_stats_kernel<false><<<dim3(nblk, C), 256, 0, (hipStream_t)stream>>>(x, nullptr, C, V, nblk, ws);
   if (int e = dpi_check_launch("channel_sum.stats")) return e;
   channel_sum_final_kernel<<<C, 64, 0, (hipStream_t)stream>>>(ws, nblk, C, out);
   return dpi_check_launch("channel_sum.final");
@@ -1046,11 +1069,17 @@ extern "C" int dpi_upsample2x_fwd_io(const float* x, const float* chain, int C, 
               "upsample_fwd: output (%d,%d,%d) exceeds 2x input (%d,%d,%d)", Do, Ho, Wo, D, H, W);
   const size_t Vo = (size_t)Do * Ho * Wo, V = (size_t)D * H * W;
   if (linear && H > 1 && W > 1 && (!scale_d || D > 1)) {
-    if (scale_d) upsample_lin_fwd_cube_kernel<true><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, y, fb, fb);
-    else upsample_lin_fwd_cube_kernel<false><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, y, fb, fb);
+    if (scale_d) {
+      if (fb) upsample_lin_fwd_cube_kernel<true, true, true><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, y);
+      else upsample_lin_fwd_cube_kernel<true, false, false><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, y);
+    } else {
+      if (fb) upsample_lin_fwd_cube_kernel<false, true, true><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, y);
+      else upsample_lin_fwd_cube_kernel<false, false, false><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, y);
+    }
     return dpi_check_launch("upsample_lin_fwd_cube");
   }
-  upsample_fwd_kernel<<<dim3(ew_blocks(Vo), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, linear, scale_d, y, fb, fb);
+  if (fb) upsample_fwd_kernel<true, true><<<dim3(ew_blocks(Vo), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, linear, scale_d, y);
+  else upsample_fwd_kernel<false, false><<<dim3(ew_blocks(Vo), C), 256, 0, (hipStream_t)stream>>>(x, chain, D, H, W, Do, Ho, Wo, linear, scale_d, y);
   return dpi_check_launch("upsample_fwd");
 }
 
@@ -1083,7 +1112,11 @@ extern "C" int dpi_upsample2x_bwd_io(const float* dy, int C, int D, int H, int W
       // enough slabs per launch to fill the chip, each workgroup then strides over the rest
       size_t gy = outer < 65535 ? outer : 65535;
       while (gy > 1 && (size_t)gx * gy > 16384) gy = (gy + 1) / 2;
-      upsample_lin_bwd_axis_kernel<<<dim3(gx, (unsigned)gy), 256, 0, st>>>(src, dst, (unsigned)outer, n, no, (unsigned)inner, ib, ob);
+      const dim3 g(gx, (unsigned)gy);
+      if (ib && ob) upsample_lin_bwd_axis_kernel<true, true><<<g, 256, 0, st>>>(src, dst, (unsigned)outer, n, no, (unsigned)inner);
+      else if (ib) upsample_lin_bwd_axis_kernel<true, false><<<g, 256, 0, st>>>(src, dst, (unsigned)outer, n, no, (unsigned)inner);
+      else if (ob) upsample_lin_bwd_axis_kernel<false, true><<<g, 256, 0, st>>>(src, dst, (unsigned)outer, n, no, (unsigned)inner);
+      else upsample_lin_bwd_axis_kernel<false, false><<<g, 256, 0, st>>>(src, dst, (unsigned)outer, n, no, (unsigned)inner);
     };
     launch(dy, t1, (size_t)C * Do * Ho, W, Wo, 1, gb, false);
     launch(t1, scale_d ? t2 : dx, (size_t)C * Do, H, Ho, W, false, scale_d ? false : gb);
@@ -1091,11 +1124,17 @@ extern "C" int dpi_upsample2x_bwd_io(const float* dy, int C, int D, int H, int W
     return dpi_check_launch("upsample_lin_bwd_axis");
   }
   if (linear) {
-    if (scale_d) upsample_lin_bwd_gather_kernel<true><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, dx, gb);
-    else upsample_lin_bwd_gather_kernel<false><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, dx, gb);
+    if (scale_d) {
+      if (gb) upsample_lin_bwd_gather_kernel<true, true><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, dx);
+      else upsample_lin_bwd_gather_kernel<true, false><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, dx);
+    } else {
+      if (gb) upsample_lin_bwd_gather_kernel<false, true><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, dx);
+      else upsample_lin_bwd_gather_kernel<false, false><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, dx);
+    }
     return dpi_check_launch("upsample_lin_bwd_gather");
   }
-  upsample_bwd_kernel<<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, linear, scale_d, dx, gb);
+  if (gb) upsample_bwd_kernel<true><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, linear, scale_d, dx);
+  else upsample_bwd_kernel<false><<<dim3(ew_blocks(V), C), 256, 0, (hipStream_t)stream>>>(dy, D, H, W, Do, Ho, Wo, linear, scale_d, dx);
   return dpi_check_launch("upsample_bwd");
 }
 
