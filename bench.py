@@ -224,10 +224,22 @@ def conv_flop(d):
 
 
 def conv_bytes(d):
-    """Algorithmic HBM bytes of one launch: read the input tensor once, write the output tensor once (fp32)."""
+    """Algorithmic HBM bytes of one launch: read the input tensor once, write the output tensor once, each in its storage type
+    (dpi_conv_desc.io: 2 bytes per element where the tensor is bf16 — a gradient shares its tensor's type —, 4 otherwise)."""
     from deep_prior_interpolation_amd.ops import desc_out_dims
     Do, Ho, Wo = desc_out_dims(d)
-    return 4.0 * (d.Cin * d.D * d.H * d.W + d.Cout * Do * Ho * Wo)
+    return (2.0 if d.io & 1 else 4.0) * d.Cin * d.D * d.H * d.W + (2.0 if d.io & 2 else 4.0) * d.Cout * Do * Ho * Wo
+
+
+def bmin_bytes(V, precision):
+    """Compulsory HBM bytes of one iteration (3 x every conv / up-sampling tensor once + Adam + noise-add + loss).  With bf16
+    activations and gradients (--precision bf16) the conv / up-sampling terms halve, the perturbed input is written as bf16 (z is read as
+    fp32), loss and Adam are unchanged: 4.79 kB instead of 9.30 kB per voxel."""
+    per_voxel = BMIN_PER_VOXEL_ITER
+    if precision == "bf16":
+        noise, loss = 2 * 64 * 4.0, 3 * 4.0
+        per_voxel = (per_voxel - noise - loss) / 2.0 + 64 * (4.0 + 2.0) + loss
+    return per_voxel * V + BMIN_CONST
 
 
 def run_c2(a, rank, world, device):
@@ -369,7 +381,7 @@ def run_c2(a, rank, world, device):
         gather_ok = gather_ok and bool(torch.isfinite(tot).item())
     ms = dt / a.steps * 1e3          # (every rank assembles the record — pure host arithmetic — because the configs[2] block below is a collective job)
     iter_flop = FLOP_PER_VOXEL_ITER * V
-    bmin = BMIN_PER_VOXEL_ITER * V + BMIN_CONST
+    bmin = bmin_bytes(V, a.precision)
     prof, traffic_stale = load_profile_json(a.precision) if tuple(a.patch) == (256, 128, 128) else (None, False)
     roof = None
     fam_rows = []
@@ -435,7 +447,18 @@ def run_c2(a, rank, world, device):
                     "launch_ms": round(best_l[2], 4), "tflops": round(best_l[3] / (best_l[2] * 1e-3) / 1e12, 2),
                     "frac": round(best_l[3] / (best_l[2] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)},
                 "families": fam_rows, "whole_iteration": whole}
-        if a.precision != "fp32":
+        if a.precision == "bf16":
+            # BASELINE configs[4]: bf16 activations + gradients in HBM, bf16 MFMA operands.  AI = 1712.6 GF / 20.2 GB = 85 FLOP/B, below the bf16
+            # ridge (2.5 PF / 8 TB/s = 312): the mode is bound by HBM, so the line is quoted on bytes.  The fp32-peak figures stay beside it.
+            gbs = d_iso["bytes"] / (d_iso["ms"] * 1e-3) / 1e9
+            gbs_t = nbytes / (t_ms * 1e-3) / 1e9
+            roof["vs_fp32_mfma_peak"] = {"achieved_tflops": roof["achieved"], "frac": roof["frac"], "frac_in_timed_schedule": roof["frac_in_timed_schedule"]}
+            roof.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "frac_in_timed_schedule": round(gbs_t / HBM_PEAK_GBS, 4),
+                         "note": "frac = the family's algorithmic bytes (input tensor read once + output tensor written once, 2 bytes per bf16 element) / sum of "
+                                 "its launch durations / 8 TB/s; the whole iteration moves %.2f GB compulsory (bf16 B_min, bench.bmin_bytes) -> "
+                                 "whole_iteration / frac_hbm" % (bmin / 1e9)})
+        elif a.precision != "fp32":
             roof["note"] = ("precision mode %s: the 3x3x3 stride-1 families run on the bf16 matrix cores (16x the fp32 rate) and are HBM-bound there "
                             "(see `families[*].algorithmic_gbs`); frac is still quoted against the fp32 peak for comparability with the fp32 line"
                             % a.precision)
@@ -443,7 +466,8 @@ def run_c2(a, rank, world, device):
     other = None
     if a.precision == "fp32" and world == 1 and mode == "eager" and not a.no_other_modes:
         other = {}
-        for prec, label in (("bf16", "bf16"), ("split", "f32 (3 x bf16 split)")):
+        for prec, label in (("bf16", "bf16 (activations + gradients stored as bf16, bf16 MFMA operands)"), ("bf16mm", "f32 storage, bf16 MFMA operands"),
+                            ("split", "f32 (3 x bf16 split)")):
             T.args.precision = prec
             for _ in range(3):
                 eager_step()
@@ -457,6 +481,7 @@ def run_c2(a, rank, world, device):
                            "steps": a.steps, "warmup": 3, "note": "python bench.py --precision %s reports this mode as its own line" % prec}
         T.args.precision = "fp32"
         ops.set_precision("fp32")
+        ops.set_storage("fp32")
     last_loss, last_snr = T.history.loss[-1], T.history.snr[-1]
     del T, acc
     torch.cuda.empty_cache()

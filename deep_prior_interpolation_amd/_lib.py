@@ -126,6 +126,7 @@ SIGNATURES = {
     "dpi_upsample2x_fwd_io": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _U, _P]),
     "dpi_upsample2x_bwd_io": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _U, _P]),
     "dpi_noise_add_io": (_I, [_P, _Z, _F, _U64, _P, _P, _U, _P]),
+    "dpi_noise_add_regen_io": (_I, [_Z, _F, _U64, _U64, _F, _U64, _P, _P, _U, _P]),
 }
 
 _lib = None

@@ -106,9 +106,12 @@ __device__ __forceinline__ void philox4(uint64_t ctr, uint64_t stream_id, uint64
   z[0] = r0 * c0; z[1] = r0 * s0; z[2] = r1 * c1; z[3] = r1 * s1;
 }
 
+// zregen: instead of READING z (zin) the kernel re-draws it — z = zstd * N(0,1) of the Philox stream (zseed, zstream), exactly the values
+// dpi_fill_normal(mean 0) wrote — so the fixed network input never has to be streamed from HBM again (1.07 GB per iteration at the bench patch).
+struct ZRegen { int on; float zstd; uint64_t zseed, zstream; };
 __global__ __launch_bounds__(256) void noise_kernel(const float* __restrict__ zin, size_t n, float mean, float std, uint64_t seed,
                                                     const uint64_t* __restrict__ step_ptr, uint64_t stream_id,
-                                                    float* __restrict__ out, bool ob = false) {        // ob: `out` is stored as bf16
+                                                    float* __restrict__ out, bool ob = false, ZRegen zr = ZRegen{0, 0.f, 0, 0}) {        // ob: `out` is stored as bf16
   typedef float nz_f32x4 __attribute__((ext_vector_type(4)));
   const uint64_t sid = step_ptr ? *step_ptr : stream_id;
   const bool vec = (n & 3) == 0;
@@ -119,14 +122,20 @@ __global__ __launch_bounds__(256) void noise_kernel(const float* __restrict__ zi
     const size_t i = q * 4;
     if (vec) {
       float4 b = make_float4(mean, mean, mean, mean);
-      if (zin) {
+      if (zr.on) {
+        float zz[4];
+        philox4(q, zr.zstream, zr.zseed, zz);
+        b = make_float4(fmaf(zr.zstd, zz[0], 0.f), fmaf(zr.zstd, zz[1], 0.f), fmaf(zr.zstd, zz[2], 0.f), fmaf(zr.zstd, zz[3], 0.f));   // bit for bit what fill_normal stored
+      } else if (zin) {
         if (nt) { const nz_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nz_f32x4*>(zin + i)); b = make_float4(v[0], v[1], v[2], v[3]); }
         else b = *reinterpret_cast<const float4*>(zin + i);
       }
       b.x = fmaf(std, z[0], b.x); b.y = fmaf(std, z[1], b.y); b.z = fmaf(std, z[2], b.z); b.w = fmaf(std, z[3], b.w);
       dpi_st4(out, i, b, ob, nt);
     } else {
-      for (int k = 0; k < 4 && i + k < n; ++k) dpi_st(out, i + k, fmaf(std, z[k], zin ? zin[i + k] : mean), ob);
+      float zz[4] = {0.f, 0.f, 0.f, 0.f};
+      if (zr.on) philox4(q, zr.zstream, zr.zseed, zz);
+      for (int k = 0; k < 4 && i + k < n; ++k) dpi_st(out, i + k, fmaf(std, z[k], zr.on ? fmaf(zr.zstd, zz[k], 0.f) : (zin ? zin[i + k] : mean)), ob);
     }
   }
 }
@@ -238,6 +247,14 @@ extern "C" int dpi_noise_add_io(const float* z, size_t n, float std, uint64_t se
   DPI_REQUIRE((io & ~3u) == 0, "noise_add: unknown storage-type bits in io = %u", io);
   noise_kernel<<<nblocks(cdivz(n, 4)), 256, 0, (hipStream_t)stream>>>(z, n, 0.f, std, seed, step_ptr, 0, out, (io & DPI_STORE_FWD_BF16) != 0);
   return dpi_check_launch("noise_add");
+}
+extern "C" int dpi_noise_add_regen_io(size_t n, float z_std, uint64_t z_seed, uint64_t z_stream_id, float std, uint64_t seed,
+                                      const uint64_t* step_ptr, float* out, unsigned io, void* stream) {
+  DPI_REQUIRE(out && n > 0, "noise_add_regen: bad argument");
+  DPI_REQUIRE((io & ~3u) == 0, "noise_add_regen: unknown storage-type bits in io = %u", io);
+  noise_kernel<<<nblocks(cdivz(n, 4)), 256, 0, (hipStream_t)stream>>>(nullptr, n, 0.f, std, seed, step_ptr, 0, out, (io & DPI_STORE_FWD_BF16) != 0,
+                                                                      ZRegen{1, z_std, z_seed, z_stream_id});
+  return dpi_check_launch("noise_add_regen");
 }
 extern "C" int dpi_noise_add(const float* z, size_t n, float std, uint64_t seed, const uint64_t* step_ptr, float* out,
                              void* stream) {

@@ -97,15 +97,19 @@ class Interpolator:
         """z = noise_std * N(0,1) of shape (1, inputdepth, *patch), optionally FIR-filtered along t (wavelet / Butterworth)
         and prepared for the data-forgetting term (main.py:59-97)."""
         a = self.args
+        philox_z = (None,)
         if a.noise_dist != "n":
             z = u.get_noise((1, a.inputdepth) + self.img.shape[:-1], a.noise_dist).to(self.device) * a.noise_std
         else:
             z = torch.empty((1, a.inputdepth) + self.img.shape[:-1], dtype=torch.float32, device=self.device)
             # stream id: high word marks "z" (the per-iteration perturbation uses the iteration counter as stream id), low word =
             # running patch count of this Interpolator, so consecutive patches do not share z
-            _lib.check(_lib.load().dpi_fill_normal(_lib.ptr(z), z.numel(), 0.0, float(a.noise_std), self.noise_seed,
-                                                   (0xFFFFFFFF << 32) | (self._patches_seen & 0xFFFFFFFF), _lib.stream()), "dpi_fill_normal")
+            zstream = (0xFFFFFFFF << 32) | (self._patches_seen & 0xFFFFFFFF)
+            _lib.check(_lib.load().dpi_fill_normal(_lib.ptr(z), z.numel(), 0.0, float(a.noise_std), self.noise_seed, zstream, _lib.stream()),
+                       "dpi_fill_normal")
+            philox_z = (z, float(a.noise_std), int(self.noise_seed), int(zstream))      # dropped below if anything rewrites z
         self._patches_seen += 1
+        self._z_philox = None
         if a.filter_noise_with_wavelet:                         # main.py:66-72
             z = u.ConvolveKernel_1d(kernel=np.load(os.path.join(a.imgdir, "wavelet.npy")), ndim=z.ndim - 2)(z)
         if a.lowpass_fs and a.lowpass_fc:                       # main.py:74-84: 4th-order Butterworth as an FIR along t
@@ -119,6 +123,9 @@ class Interpolator:
             self.add_data_ = data_
             self.add_data_weight = np.logspace(0, -4, a.data_forgetting_factor)
         self.input_ = z
+        # z is still the plain Philox fill: the per-iteration perturbation can re-draw it instead of reading it (dpi_noise_add_regen_io)
+        if a.noise_dist == "n" and z is philox_z[0] and os.environ.get("DPI_NO_Z_REGEN") is None:
+            self._z_philox = philox_z
 
     # ------------------------------------------------------------------------------------------
     def perturbed_input(self):
@@ -130,6 +137,12 @@ class Interpolator:
         bf = ops.STORAGE_BF16 and self.input_.ndim == 5
         out = torch.empty_like(self.input_, dtype=torch.bfloat16) if bf else torch.empty_like(self.input_)
         self._noise_step += 1
+        zp = getattr(self, "_z_philox", None)
+        if zp is not None and zp[0] is self.input_:
+            _lib.check(_lib.load().dpi_noise_add_regen_io(out.numel(), zp[1], zp[2], zp[3], float(self.args.reg_noise_std), self.noise_seed,
+                                                          _lib.ptr(self._noise_step), _lib.ptr(out), _lib.STORE_FWD_BF16 if bf else 0,
+                                                          _lib.stream()), "dpi_noise_add_regen")
+            return out
         _lib.check(_lib.load().dpi_noise_add_io(_lib.ptr(self.input_), out.numel(), float(self.args.reg_noise_std),
                                                 self.noise_seed, _lib.ptr(self._noise_step), _lib.ptr(out),
                                                 _lib.STORE_FWD_BF16 if bf else 0, _lib.stream()), "dpi_noise_add")

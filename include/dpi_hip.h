@@ -343,6 +343,11 @@ int dpi_noise_add(const float* z, size_t n, float std, uint64_t seed, const uint
                   float* out, void* stream);
 int dpi_fill_normal(float* out, size_t n, float mean, float std, uint64_t seed, uint64_t stream_id,
                     void* stream);
+/* dpi_noise_add for a z that IS such a fill (z = dpi_fill_normal(mean 0, z_std, z_seed, z_stream_id), untouched since): the kernel re-draws z
+ * from its Philox stream instead of reading it — out = z + std * N(0,1) with the same bits as dpi_noise_add_io(z, ...), minus the HBM read of
+ * z (64 channels at full resolution, every iteration).  io: DPI_STORE_FWD_BF16 = out is bf16. */
+int dpi_noise_add_regen_io(size_t n, float z_std, uint64_t z_seed, uint64_t z_stream_id, float std, uint64_t seed,
+                           const uint64_t* step_ptr, float* out /*F*/, unsigned io, void* stream);
 /* Replaces utils/processing.py:34-67 (ConvolveKernel_1d: grouped conv_transposeNd with a 1-D kernel along the time
  * axis, used by --filter_noise_with_wavelet / --lowpass_*): y[c][t][s] = sum_k taps[k] * x[c][t + K/2 - k][s],
  * x: [C][T][S] with S = product of the remaining spatial axes; K odd; taps on the device. */

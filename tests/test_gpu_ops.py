@@ -1034,3 +1034,35 @@ def test_conv_q4_chain_stats_and_unaligned_rows(ops, q4_forced, cin, cout, shape
         p = part.view(nblk, cout, 2).sum(0).cpu()
         np.testing.assert_allclose(p[:, 0].numpy(), yr.sum((0, 2, 3, 4)).numpy(), rtol=1e-5, atol=2e-2)
         np.testing.assert_allclose(p[:, 1].numpy(), (yr ** 2).sum((0, 2, 3, 4)).numpy(), rtol=1e-5)
+
+
+def test_noise_add_with_regenerated_z_is_bit_identical():
+    """dpi_noise_add_regen_io re-draws the fixed input z from its Philox stream instead of reading it (main.py:62-64 draws z once, main.py:148-150
+    adds the perturbation every iteration): same bits as dpi_noise_add on the stored z, fp32 and bf16 output, ragged length; and the Interpolator
+    takes that path exactly while input_ is the untouched fill."""
+    from deep_prior_interpolation_amd._lib import check, load, ptr, stream
+    L = load()
+    for n in (4 * 4096, 4099):
+        z = torch.empty(n, device=DEV)
+        check(L.dpi_fill_normal(ptr(z), n, 0.0, 0.1, 11, (0xFFFFFFFF << 32) | 3, stream()))
+        step = torch.tensor([5], dtype=torch.int64, device=DEV)
+        for io, dt in ((0, torch.float32), (1, torch.bfloat16)):
+            a, b = torch.empty(n, dtype=dt, device=DEV), torch.empty(n, dtype=dt, device=DEV)
+            check(L.dpi_noise_add_io(ptr(z), n, 0.03, 11, ptr(step), ptr(a), io, stream()))
+            check(L.dpi_noise_add_regen_io(n, 0.1, 11, (0xFFFFFFFF << 32) | 3, 0.03, 11, ptr(step), ptr(b), io, stream()))
+            assert torch.equal(a.view(torch.int16 if io else torch.int32), b.view(torch.int16 if io else torch.int32))
+    from deep_prior_interpolation_amd import utils as u
+    from deep_prior_interpolation_amd.main import Interpolator
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    args = parse_arguments(["--imgdir", "x", "--datadim", "3d", "--filters", "4", "8", "--skip", "4", "--inputdepth", "6", "--epochs", "2", "--gpu", "0"])
+    u.set_seed(0)
+    T = Interpolator(args, "/tmp")
+    rng = np.random.RandomState(0)
+    T.load_data({"image": rng.randn(8, 8, 12, 1), "mask": np.ones((8, 8, 12, 1)), "name": "0"})
+    T.build_input()
+    assert T._z_philox is not None and T._z_philox[0] is T.input_
+    got = T.perturbed_input()
+    T._z_philox = None
+    T._noise_step -= 1
+    ref = T.perturbed_input()
+    assert torch.equal(got, ref)
