@@ -70,8 +70,9 @@ __device__ __forceinline__ float from_next_lane(float v) {            // lane j 
 //         do not overlap well.  Tried without gain: a second register stage of prefetch; an 8-wave workgroup whose wave pairs
 //         share a dY row and split the six products (all waves still stage and multiply in the same phases — it needs
 //         producer / consumer waves, not a symmetric split).
-template <int NS, int TH>
+template <int NS, int TH, bool XB = false, bool DYB = false>        // XB / DYB: x / dy stored as bf16 (template parameters, as in conv_bf16_mfma.hip)
 __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void conv_bf16_bwd_weight_kernel(BwBArgs a) {
+  a.xb = XB; a.dyb = DYB;
   constexpr int XR = TH + 2;                    // X rows of a slice (halo in h)
   constexpr int XSLOT = XR * ROWW;              // one X slice of the ring
   constexpr int DCOPY = TH * ROWW;              // one shifted copy of the dY slice
@@ -335,6 +336,7 @@ static BwBPlan bf16_bww_plan(const dpi_conv_desc* d) {
 // 212->128 @32x16x16 0.26 -> 0.065, 142->213 @16x8x8 0.090 -> 0.036: faster everywhere, so no size threshold.
 bool dpi_conv_bf16_bww_usable(const dpi_conv_desc* d) {
   if (d->precision < 1 || d->k != 3 || d->kd != 3 || d->stride != 1 || (d->W & 3)) return false;
+  if (d->precision == 2 && (d->io & (DPI_IO_X_BF16 | DPI_IO_DY_BF16))) return false;       // the split instantiation is compiled for fp32 tensors
   // split mode is matrix-bound (6 MFMAs per tap on 16 x 16 channel blocks): it beats the fp32 kernels where both channel counts
   // fill a block (25->16 1.20 -> 0.77 ms, 51->32 0.48 -> 0.34, 105->64 0.28 -> 0.19, 212->128 0.26 -> 0.19) and loses on the
   // few-channel layers (64->4 0.62 -> 1.29, 8->13 0.33 -> 0.37, 137->8 0.33 -> 0.41), which keep the fp32 kernels
@@ -349,6 +351,9 @@ int dpi_conv_bf16_bww_run(const dpi_conv_desc* d, const float* x, const float* c
   BwBArgs a{x, chain, dy, ws, d->Cin, d->Cout, d->D, d->H, d->W, p.nth, p.ntw, p.ndc, p.dlen, (d->io & DPI_IO_X_BF16) != 0, (d->io & DPI_IO_DY_BF16) != 0};
   dim3 grid(p.nchunks, cdiv(d->Cin, 16), cdiv(d->Cout, 16));
   if (d->precision == 2) conv_bf16_bwd_weight_kernel<3, 4><<<grid, 256, 0, st>>>(a);
+  else if (a.xb && a.dyb) conv_bf16_bwd_weight_kernel<1, 8, true, true><<<grid, 256, 0, st>>>(a);
+  else if (a.xb) conv_bf16_bwd_weight_kernel<1, 8, true, false><<<grid, 256, 0, st>>>(a);
+  else if (a.dyb) conv_bf16_bwd_weight_kernel<1, 8, false, true><<<grid, 256, 0, st>>>(a);
   else conv_bf16_bwd_weight_kernel<1, 8><<<grid, 256, 0, st>>>(a);
   if (int e = dpi_check_launch("conv_bf16_bwd_weight")) return e;
   dpi_reduce_chunks(ws, dw, (size_t)d->Cout * d->Cin * 27, p.nchunks, st);

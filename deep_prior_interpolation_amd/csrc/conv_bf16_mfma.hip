@@ -94,8 +94,11 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, uns
   l = pack_bf16(s0, s1);
 }
 
-template <int KD, int NR, int NH, bool FLIP, int NS = 1>
+// XB / YB: storage type of x / y (true = bf16) as TEMPLATE parameters: as run-time flags they cost the fp32-tensor instantiation 10 % (and the
+// storage mode as much), measured in the iteration (profiles/README.md, round 4).
+template <int KD, int NR, int NH, bool FLIP, int NS = 1, bool XB = false, bool YB = false>
 __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
+  a.xb = XB; a.yb = YB;
   using G = GeoB<KD, NR, NH>;
   constexpr int TAPS = G::TAPS, NTG = G::NTG, PD = (KD - 1) / 2, NT = NR * NH;
   constexpr int XW = G::TILE * 4, WW = NTG * 64 * 8;                        // words / halfwords per operand copy
@@ -380,7 +383,10 @@ static bool bf16_pays(const dpi_conv_desc* d, bool flip) {
   return nr == 4 && (cin > 4 || cout > 16);      // 4 -> 8 forward: 217 vs 196 us (fp32); 4 -> 67 (backward-data of 67 -> 4): 888 vs 1056 us
 }
 
-bool dpi_conv_bf16_usable(const dpi_conv_desc* d, bool flip) { return d->precision >= 1 && d->k == 3 && d->stride == 1 && bf16_pays(d, flip); }
+bool dpi_conv_bf16_usable(const dpi_conv_desc* d, bool flip) {
+  if (d->precision == 2 && (dpi_io_in(d, flip) || dpi_io_out(d, flip))) return false;      // the split instantiations are compiled for fp32 tensors
+  return d->precision >= 1 && d->k == 3 && d->stride == 1 && bf16_pays(d, flip);
+}
 
 int dpi_conv_bf16_stat_blocks(const dpi_conv_desc* d) {
   int nr, nh, a, b, c;
@@ -388,12 +394,21 @@ int dpi_conv_bf16_stat_blocks(const dpi_conv_desc* d) {
   return bf16_tiles(d, nr, nh, &a, &b, &c);
 }
 
+template <int KD, bool FLIP, int NS, bool XB = false, bool YB = false>
+static void launch_bf16_t(const BArgs& a, int nr, int nh, dim3 grid, hipStream_t st) {
+  if (nr == 4 && nh == 2) conv_bf16_kernel<KD, 4, 2, FLIP, NS, XB, YB><<<grid, 256, 0, st>>>(a);
+  else if (nr == 4) conv_bf16_kernel<KD, 4, 1, FLIP, NS, XB, YB><<<grid, 256, 0, st>>>(a);
+  else if (nh == 2) conv_bf16_kernel<KD, 2, 2, FLIP, NS, XB, YB><<<grid, 256, 0, st>>>(a);
+  else conv_bf16_kernel<KD, 2, 1, FLIP, NS, XB, YB><<<grid, 256, 0, st>>>(a);
+}
 template <int KD, bool FLIP, int NS>
 static void launch_bf16(const BArgs& a, int nr, int nh, dim3 grid, hipStream_t st) {
-  if (nr == 4 && nh == 2) conv_bf16_kernel<KD, 4, 2, FLIP, NS><<<grid, 256, 0, st>>>(a);
-  else if (nr == 4) conv_bf16_kernel<KD, 4, 1, FLIP, NS><<<grid, 256, 0, st>>>(a);
-  else if (nh == 2) conv_bf16_kernel<KD, 2, 2, FLIP, NS><<<grid, 256, 0, st>>>(a);
-  else conv_bf16_kernel<KD, 2, 1, FLIP, NS><<<grid, 256, 0, st>>>(a);
+  if constexpr (NS == 1) {          // (split mode takes fp32 tensors only: dpi_conv_bf16_usable)
+    if (a.xb && a.yb) { launch_bf16_t<KD, FLIP, NS, true, true>(a, nr, nh, grid, st); return; }
+    if (a.xb) { launch_bf16_t<KD, FLIP, NS, true, false>(a, nr, nh, grid, st); return; }
+    if (a.yb) { launch_bf16_t<KD, FLIP, NS, false, true>(a, nr, nh, grid, st); return; }
+  }
+  launch_bf16_t<KD, FLIP, NS, false, false>(a, nr, nh, grid, st);
 }
 
 int dpi_conv_bf16_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
