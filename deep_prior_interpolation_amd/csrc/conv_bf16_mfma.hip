@@ -43,6 +43,15 @@ struct BArgs {
   int accumulate;
   int debug;     // tuning experiments only (dpi_set_bf16_debug): 1 skip the MFMA phase, 2 skip the global loads, 4 skip the LDS stores
   int xb, yb;    // storage type of x / y in HBM: 1 = bf16 (dpi_conv_desc.io), 0 = fp32
+  // second input through a 1x1x1 kernel at the OUTPUT positions (x2 != nullptr; backward-data launches only): y += W2 * x2 with
+  // x2 [C2][D][H][W] of x's storage type and W2[co][c] = w2[co * w2_co_stride + c * w2_c_stride] — the input gradient of a 3x3x3 layer and the
+  // 1x1x1 layer beside it (Block3d.conv1 + shortcut, ResPath3d.conv3x3 + conv1x1, mulresunet.py:72-113) in ONE pass over dx, as MfmaSecond
+  // does for the fp32 kernel.  Without it the pair is two launches: the 1x1x1 one writes dx, this one reads it back and adds (67->4 + 67->25
+  // at 256x128x128 with bf16 tensors: 0.51 + 1.14 ms, of which 0.73 ms are that read-back; fused: one launch).
+  const float* __restrict__ x2;
+  const float* __restrict__ w2;
+  int C2;
+  long w2_co_stride, w2_c_stride;
 };
 
 template <int KD, int NR, int NH>
@@ -284,6 +293,76 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
     }
   }
 
+  if constexpr (FLIP && NS == 1 && KD == 3) if (a.x2 != nullptr) {
+    // 16 channels of x2 per step: two [position][8 channels] planes of the tile's OUTPUT positions (no halo) in the operand buffer; lane slot
+    // lk < 2 multiplies plane lk (K = 32 with 16 real channels: the A fragments of slots 2, 3 are zero, their B reads repeat planes 0, 1)
+    constexpr int NPOS = G::TZ * G::TY * G::TW, E2 = (NPOS + 255) / 256;
+    static_assert(2 * NPOS <= G::TILE, "the second input reuses the halo-tile buffer");
+    int g2[E2];
+#pragma unroll
+    for (int e = 0; e < E2; ++e) {
+      const int idx = tid + e * 256;
+      const int col = idx % G::TW, row = idx / G::TW;
+      const int hy = row % G::TY, dz = row / G::TY;
+      const int od = od0 + dz, oh = oh0 + hy, ow = ow0 + col;
+      g2[e] = (idx < NPOS && od < Do && oh < Ho && ow < Wo) ? (od * Ho + oh) * Wo + ow : -1;
+    }
+    for (int c0 = 0; c0 < a.C2; c0 += 16) {
+      float s2[16][E2], w2q[2];
+      if (XB) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const __amdgpu_buffer_rsrc_t r = dpi_buffer_t(dpi_at(a.x2, (size_t)min(c0 + c, a.C2 - 1) * Vo, true), Vo, true);
+#pragma unroll
+          for (int e = 0; e < E2; ++e) s2[c][e] = dpi_buffer_load_bf16_raw(r, g2[e]);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const __amdgpu_buffer_rsrc_t r = dpi_buffer(a.x2 + (size_t)min(c0 + c, a.C2 - 1) * Vo, Vo * sizeof(float));
+#pragma unroll
+          for (int e = 0; e < E2; ++e) s2[c][e] = dpi_buffer_load(r, g2[e] * 4);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int q = tid + j * 256;                             // A fragment element (lane64 = q >> 3, i = q & 7)
+        const int i = q & 7, l64 = q >> 3;
+        const int co = n0 + (l64 & 15), c = c0 + 8 * (l64 >> 4) + i;
+        const bool ok = (l64 >> 4) < 2 && co < a.Cout && c < a.C2;
+        const float v = a.w2[(ok ? co : 0) * a.w2_co_stride + (ok ? c : 0) * a.w2_c_stride];
+        w2q[j] = ok ? v : 0.f;
+      }
+      __syncthreads();                                           // the main loop's last group (or the previous step) has been read
+#pragma unroll
+      for (int e = 0; e < E2; ++e) {
+        const int idx = tid + e * 256;
+        if ((e + 1) * 256 <= NPOS || idx < NPOS) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            if (XB) {
+              auto pr = [](float lo, float hi) { return __builtin_bit_cast(unsigned, lo) | (__builtin_bit_cast(unsigned, hi) << 16); };
+              *reinterpret_cast<u32x4*>(xl + (g * NPOS + idx) * 4) = (u32x4){pr(s2[8 * g][e], s2[8 * g + 1][e]), pr(s2[8 * g + 2][e], s2[8 * g + 3][e]),
+                                                                             pr(s2[8 * g + 4][e], s2[8 * g + 5][e]), pr(s2[8 * g + 6][e], s2[8 * g + 7][e])};
+            } else {
+              *reinterpret_cast<u32x4*>(xl + (g * NPOS + idx) * 4) = (u32x4){pack_bf16(s2[8 * g][e], s2[8 * g + 1][e]), pack_bf16(s2[8 * g + 2][e], s2[8 * g + 3][e]),
+                                                                             pack_bf16(s2[8 * g + 4][e], s2[8 * g + 5][e]), pack_bf16(s2[8 * g + 6][e], s2[8 * g + 7][e])};
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wl[tid + j * 256] = (unsigned short)bf16_bits(w2q[j]);
+      __syncthreads();
+      const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wl + lane * 8));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int p2 = ((wz * G::TY + wh + t / NH) * G::TW + (t % NH) * 16 + lj) + (lk & 1) * NPOS;
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xl + p2 * 4)), acc[t], 0, 0, 0);
+      }
+    }
+  }
+
   // ---- epilogue: D row = co (4*lk + r), D col = voxel lj (same layout as the fp32 16x16x4 MFMA) ---------------------------
   const bool interior = od0 + G::TZ <= Do && oh0 + G::TY <= Ho && ow0 + G::TW <= Wo && n0 + 16 <= a.Cout;
   const int vbase = ((od0 + wz) * Ho + oh0 + wh) * Wo + ow0 + lj;
@@ -388,6 +467,9 @@ bool dpi_conv_bf16_usable(const dpi_conv_desc* d, bool flip) {
   return d->precision >= 1 && d->k == 3 && d->stride == 1 && bf16_pays(d, flip);
 }
 
+// whether dpi_conv_bf16_run adds a 1x1x1 second input in the same pass: bf16 arithmetic mode, 3-D, backward-data
+bool dpi_conv_bf16_second_ok(const dpi_conv_desc* d, bool flip) { return flip && d->precision == 1 && d->kd == 3 && dpi_conv_bf16_usable(d, flip); }
+
 int dpi_conv_bf16_stat_blocks(const dpi_conv_desc* d) {
   int nr, nh, a, b, c;
   bf16_variant(d, d->Cout, &nr, &nh);
@@ -412,14 +494,15 @@ static void launch_bf16(const BArgs& a, int nr, int nh, dim3 grid, hipStream_t s
 }
 
 int dpi_conv_bf16_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
-                      double* partials, bool flip, int accumulate, hipStream_t st) {
+                      double* partials, bool flip, int accumulate, hipStream_t st, const MfmaSecond* sec) {
   const int taps = d->kd * 9;
   const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
   const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
   int nr, nh;
   bf16_variant(d, cout, &nr, &nh);
   BArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, accumulate, g_bf16_debug,
-          dpi_io_in(d, flip), dpi_io_out(d, flip)};
+          dpi_io_in(d, flip), dpi_io_out(d, flip), nullptr, nullptr, 0, 0, 0};
+  if (sec) { a.x2 = sec->x2; a.w2 = sec->w2; a.C2 = sec->C2; a.w2_co_stride = sec->w2_co_stride; a.w2_c_stride = sec->w2_c_stride; }
   const int ntiles = bf16_tiles(d, nr, nh, &a.ntd, &a.nth, &a.ntw);
   dim3 grid(ntiles, cdiv(cout, 16));
   if (d->precision == 2) {

@@ -476,7 +476,8 @@ bool dpi_mfma_half_tile(const dpi_conv_desc* d, bool flip);
 bool dpi_conv_bf16_usable(const dpi_conv_desc* d, bool flip);
 int dpi_conv_bf16_stat_blocks(const dpi_conv_desc* d);
 int dpi_conv_bf16_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
-                      double* partials, bool flip, int accumulate, hipStream_t st);
+                      double* partials, bool flip, int accumulate, hipStream_t st, const MfmaSecond* sec = nullptr);
+bool dpi_conv_bf16_second_ok(const dpi_conv_desc* d, bool flip);
 static int g_mfma_min_cout = 8;
 extern "C" void dpi_set_mfma_min_cout(int n) { g_mfma_min_cout = n; }
 
@@ -594,6 +595,12 @@ extern "C" int dpi_conv_bwd_data_dual(const dpi_conv_desc* d3, const float* dy3,
   DPI_REQUIRE(d3->k == 3 && d1->k == 1 && d3->stride == 1 && d1->stride == 1, "conv_bwd_data_dual: needs a 3x3(x3) and a 1x1(x1) stride-1 layer");
   DPI_REQUIRE(d3->Cin == d1->Cin && d3->D == d1->D && d3->H == d1->H && d3->W == d1->W, "conv_bwd_data_dual: the two layers read different tensors");
   hipStream_t st = (hipStream_t)stream;
+  DPI_REQUIRE((d3->io & (DPI_IO_DX_BF16 | DPI_IO_X_BF16)) == (d1->io & (DPI_IO_DX_BF16 | DPI_IO_X_BF16)), "conv_bwd_data_dual: the two layers disagree on the storage type of their input");
+  if (g_dual && dpi_conv_bf16_second_ok(d3, true) && (d3->io & DPI_IO_DY_BF16) == (d1->io & DPI_IO_DY_BF16)) {
+    // bf16 arithmetic mode: the 1x1x1 term as extra K blocks of the bf16-MFMA kernel (conv_bf16_mfma.hip)
+    const MfmaSecond sec{dy1, w1, d1->Cout, 1, (long)d1->Cin};
+    return dpi_conv_bf16_run(d3, dy3, nullptr, w3, nullptr, dx, nullptr, true, accumulate, st, &sec);
+  }
   if (g_dual && takes_mfma_path(d3, true) && dpi_conv_mfma_second_ok(d3, true, d1->Cout, ws != nullptr)) {
     // W2[ci][co1] = w1[co1][ci]: rows of this launch are the layers' INPUT channels
     const MfmaSecond sec{dy1, w1, d1->Cout, 1, (long)d1->Cin};

@@ -206,6 +206,44 @@ def test_conv_chain_on_bf16_input_and_dual_backward(ops):
     half_ulp_ok(dx, g3 + xr.grad, "dx (dual)", slack=1.01)
 
 
+@pytest.mark.parametrize("store", ["bf16", "fp32"])
+@pytest.mark.parametrize("cin,c3,c1,shape,acc", [(67, 4, 25, (32, 64, 64), False), (25, 16, 25, (64, 64, 64), True), (21, 8, 16, (32, 64, 64), False),
+                                                 (40, 32, 35, (32, 32, 64), True)])
+def test_dual_backward_fused_into_the_bf16_kernel(ops, cin, c3, c1, shape, acc, store):
+    """dpi_conv_bwd_data_dual in the bf16 arithmetic mode on big-tile shapes: the 1x1x1 layer's term runs as extra K blocks of
+    conv_bf16_kernel (one pass over dx) — bf16 and fp32 tensors, with and without gradient fan-in, C2 = 16 (one step), 25 / 35 (ragged steps).
+    Operands are bf16-representable, so the single rounding of the fused pass keeps a bf16 result within half an ulp of the fp64 oracle."""
+    ops.set_precision("bf16mm")
+    gen = torch.Generator().manual_seed(cin + c1)
+    adt = BF if store == "bf16" else torch.float32
+    w3 = bf16_values((c3, cin, 3, 3, 3), gen, 0.05)
+    w1 = bf16_values((c1, cin, 1, 1, 1), gen, 0.2)
+    dy3 = bf16_values((1, c3) + shape, gen)
+    dy1 = bf16_values((1, c1) + shape, gen)
+    base = bf16_values((1, cin) + shape, gen)
+    xr = torch.zeros((1, cin) + shape, dtype=torch.float64, requires_grad=True)
+    ((O.conv_nd(xr, w3.double(), None, 1) * dy3.double()).sum() + (O.conv_nd(xr, w1.double(), None, 1) * dy1.double()).sum()).backward()
+    ref = xr.grad + (base.double() if acc else 0.0)
+    xproto = torch.empty((1, cin) + shape, dtype=adt, device=DEV)
+    d3 = ops.make_desc(xproto, w3.to(DEV), 1, adt)
+    d1 = ops.make_desc(xproto, w1.to(DEV), 1, adt)
+    dx = base.to(DEV).to(adt) if acc else torch.empty_like(xproto)
+    ops.raw_conv_bwd_data_dual(d3, dy3.to(DEV).to(adt), w3.to(DEV), d1, dy1.to(DEV).to(adt), w1.to(DEV), dx, accumulate=acc)
+    if store == "bf16":
+        half_ulp_ok(dx, ref, "dx (fused dual)")
+    else:
+        assert rel(dx, ref) < 2e-6, rel(dx, ref)
+    # the library really took one launch: with the fusion switched off the same call must give the two-launch result (two roundings in bf16)
+    L = ops._lib.load()
+    L.dpi_set_dual_bwd_data(0)
+    try:
+        dx2 = base.to(DEV).to(adt) if acc else torch.empty_like(xproto)
+        ops.raw_conv_bwd_data_dual(d3, dy3.to(DEV).to(adt), w3.to(DEV), d1, dy1.to(DEV).to(adt), w1.to(DEV), dx2, accumulate=acc)
+    finally:
+        L.dpi_set_dual_bwd_data(1)
+    assert rel(dx2.float(), ref) < (6e-3 if store == "bf16" else 2e-6)
+
+
 def test_unknown_io_bits_are_rejected(ops):
     L = ops._lib.load()
     x = torch.zeros((1, 4, 4, 4, 4), device=DEV)

@@ -35,7 +35,8 @@ def main():
     ap.add_argument("--mfma-min-cout", type=int, default=None)
     ap.add_argument("--bw-mfma-min-cout", type=int, default=None)
     ap.add_argument("--which", nargs="*", default=["fwd", "bwd_data", "bwd_weight"])
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "split"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16mm", "split"])
+    ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"], help="storage type of the activation / gradient tensors (dpi_conv_desc.io)")
     ap.add_argument("--bf16-debug", type=int, default=0)
     ap.add_argument("--bw-want", type=int, default=0, help="backward-weight plan: workgroups aimed at (dpi_set_bw_tuning)")
     ap.add_argument("--bw-xcd", type=int, default=-1, help="backward-weight plan: XCD-aware workgroup order 0/1")
@@ -62,18 +63,19 @@ def main():
     for name in a.cases:
         cin, cout, k, s, lvl = CASES[name]
         shp = tuple(max(1, n >> lvl) for n in a.shape)
-        x = torch.randn((1, cin) + shp, device=dev)
+        adt = torch.bfloat16 if a.storage == "bf16" else torch.float32
+        x = torch.randn((1, cin) + shp, device=dev).to(adt)
         w = torch.randn((cout, cin, k, k, k), device=dev) * 0.05
         b = torch.randn(cout, device=dev)
-        d = ops.make_desc(x, w, s)
+        d = ops.make_desc(x, w, s, adt)
         osh = ops.desc_out_dims(d)
-        y = torch.empty((1, cout) + osh, device=dev)
-        dy = torch.randn_like(y)
+        y = torch.empty((1, cout) + osh, device=dev, dtype=adt)
+        dy = torch.randn((1, cout) + osh, device=dev).to(adt)
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         vo = osh[0] * osh[1] * osh[2]
         flop = 2.0 * cin * k ** 3 * cout * vo
-        byt = 4.0 * (x.numel() + y.numel())
+        byt = x.element_size() * float(x.numel() + y.numel())
         fns = {"fwd": lambda: ops.raw_conv_fwd(d, x, None, w, b, y), "bwd_data": lambda: ops.raw_conv_bwd_data(d, dy, w, dx, accumulate=a.accumulate),
                "bwd_weight": lambda: ops.raw_conv_bwd_weight(d, x, None, dy, dw)}
         for which in a.which:
