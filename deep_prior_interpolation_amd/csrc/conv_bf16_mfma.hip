@@ -191,17 +191,8 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (a.accumulate) {                                          // gradient fan-in: start from the destination
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = n0 + 4 * lk + r;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
-        if (co < a.Cout && od < Do && oh < Ho && ow < Wo) acc[t][r] = dpi_ld(a.y, (size_t)co * Vo + ((size_t)od * Ho + oh) * Wo + ow, a.yb);
-      }
-    }
-  }
+  // (gradient fan-in — accumulate — reads the destination in the EPILOGUE: loads left pending on the accumulator registers here put an
+  //  s_waitcnt vmcnt(0) in front of the first MFMA, i.e. behind the whole first prefetch; measured on the Block3d fan-in launches)
 
   for (int c0 = 0; c0 < a.Cin; c0 += 8) {
     __syncthreads();                                           // everyone is done reading the previous group
@@ -366,6 +357,25 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
   // ---- epilogue: D row = co (4*lk + r), D col = voxel lj (same layout as the fp32 16x16x4 MFMA) ---------------------------
   const bool interior = od0 + G::TZ <= Do && oh0 + G::TY <= Ho && ow0 + G::TW <= Wo && n0 + 16 <= a.Cout;
   const int vbase = ((od0 + wz) * Ho + oh0 + wh) * Wo + ow0 + lj;
+  if (a.accumulate) {                                          // all of the tile's destination values requested together, then added
+    float old[4][NT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = n0 + 4 * lk + r;
+      const float* __restrict__ yo = dpi_at(a.y, (size_t)(co < a.Cout ? co : 0) * Vo + vbase, a.yb);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
+        const bool ok = interior || (co < a.Cout && od < Do && oh < Ho && ow < Wo);
+        const size_t o = (t / NH) * Wo + (t % NH) * 16;
+        old[r][t] = ok ? (YB ? __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(yo)[o]) : yo[o]) : 0.f;     // bf16: raw, widened below
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][r] += YB ? dpi_widen_raw(old[r][t]) : old[r][t];
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int co = n0 + 4 * lk + r;

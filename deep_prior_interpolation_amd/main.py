@@ -123,8 +123,10 @@ class Interpolator:
             self.add_data_ = data_
             self.add_data_weight = np.logspace(0, -4, a.data_forgetting_factor)
         self.input_ = z
-        # z is still the plain Philox fill: the per-iteration perturbation can re-draw it instead of reading it (dpi_noise_add_regen_io)
-        if a.noise_dist == "n" and z is philox_z[0] and os.environ.get("DPI_NO_Z_REGEN") is None:
+        # z is still the plain Philox fill: the per-iteration perturbation COULD re-draw it instead of reading it (dpi_noise_add_regen_io,
+        # DPI_Z_REGEN=1).  Off by default — measured slower: a second Philox4x32-10 + Box-Muller per four elements makes the pass ALU-bound
+        # (0.45 ms at 256x128x128 x 64 channels against 0.36-0.41 ms for reading z: 134 M normal deviates per iteration either way)
+        if a.noise_dist == "n" and z is philox_z[0] and os.environ.get("DPI_Z_REGEN") == "1":
             self._z_philox = philox_z
 
     # ------------------------------------------------------------------------------------------

@@ -1036,10 +1036,10 @@ def test_conv_q4_chain_stats_and_unaligned_rows(ops, q4_forced, cin, cout, shape
         np.testing.assert_allclose(p[:, 1].numpy(), (yr ** 2).sum((0, 2, 3, 4)).numpy(), rtol=1e-5)
 
 
-def test_noise_add_with_regenerated_z_is_bit_identical():
+def test_noise_add_with_regenerated_z_is_bit_identical(monkeypatch):
     """dpi_noise_add_regen_io re-draws the fixed input z from its Philox stream instead of reading it (main.py:62-64 draws z once, main.py:148-150
     adds the perturbation every iteration): same bits as dpi_noise_add on the stored z, fp32 and bf16 output, ragged length; and the Interpolator
-    takes that path exactly while input_ is the untouched fill."""
+    takes that path (opt-in, DPI_Z_REGEN=1) exactly while input_ is the untouched fill."""
     from deep_prior_interpolation_amd._lib import check, load, ptr, stream
     L = load()
     for n in (4 * 4096, 4099):
@@ -1059,6 +1059,9 @@ def test_noise_add_with_regenerated_z_is_bit_identical():
     T = Interpolator(args, "/tmp")
     rng = np.random.RandomState(0)
     T.load_data({"image": rng.randn(8, 8, 12, 1), "mask": np.ones((8, 8, 12, 1)), "name": "0"})
+    T.build_input()
+    assert T._z_philox is None                                  # off by default (measured slower: the pass becomes ALU-bound)
+    monkeypatch.setenv("DPI_Z_REGEN", "1")
     T.build_input()
     assert T._z_philox is not None and T._z_philox[0] is T.input_
     got = T.perturbed_input()
