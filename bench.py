@@ -424,7 +424,12 @@ def run_c2(a, rank, world, device):
         # this process, same tensors, the weight-gradient side stream off).  In the timed region the weight gradients share the chip with
         # the backward-data chain on another stream; their event-bracketed durations there (`in_timed_region`) then measure the sharing,
         # not the kernel — they are reported beside it.  For families that never leave the main stream the two agree.
-        roof = {"bound": "mfma", "kernel": FAMILY_NAMES.get(dom_key, str(dom_key)) + " @%dx%dx%d: the kernel family with the largest share of the iteration"
+        fam_name = FAMILY_NAMES.get(dom_key, str(dom_key))
+        if a.precision in ("bf16", "bf16mm") and dom_key[1:] == (3, 1):       # the bf16 arithmetic modes serve this family with their own kernels
+            fam_name = {"conv_fwd": "forward 3x3x3 stride 1 (conv_bf16_kernel<3,..> on the big tiles, conv_mfma_kernel below)",
+                        "conv_bwd_data": "backward-data 3x3x3 stride 1 (conv_bf16_kernel<3,..,FLIP> with the 1x1x1 siblings fused in, conv_mfma_kernel on the coarse levels)",
+                        "conv_bwd_weight": "backward-weight 3x3x3 stride 1 (conv_bf16_bwd_weight_kernel)"}[dom_key[0]]
+        roof = {"bound": "mfma", "kernel": fam_name + " @%dx%dx%d: the kernel family with the largest share of the iteration"
                          % tuple(a.patch),
                 "achieved": round(iso, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(iso / FP32_PEAK_TFLOPS, 4),
                 "frac_in_timed_schedule": round(ach / FP32_PEAK_TFLOPS, 4),

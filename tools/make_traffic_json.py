@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import kernel_source_sha256  # noqa: E402  (digest of the kernel sources: bench.py refuses a counter file of another build)
+from bench import bmin_bytes, kernel_source_sha256  # noqa: E402  (digest of the kernel sources: bench.py refuses a counter file of another build)
 
 pre, iters = sys.argv[1], int(sys.argv[2])
 precision = sys.argv[3] if len(sys.argv) > 3 else "fp32"
@@ -60,8 +60,8 @@ out = {
     "csrc_sha256": kernel_source_sha256(),
     "libdpi_hip_so_sha256": hashlib.sha256(open(os.path.join(ROOT, "deep_prior_interpolation_amd", "libdpi_hip.so"), "rb").read()).hexdigest(),
     "whole_iteration": {"FETCH_SIZE_KB_per_iteration": f_it, "WRITE_SIZE_KB_per_iteration": w_it, "read_bytes": read_b, "write_bytes": write_b,
-                        "hbm_bytes_per_iteration": read_b + write_b, "algorithmic_bytes_per_iteration": 39.18e9,
-                        "measured_over_algorithmic": round((read_b + write_b) / 39.18e9, 3),
+                        "hbm_bytes_per_iteration": read_b + write_b, "algorithmic_bytes_per_iteration": bmin_bytes(256 * 128 * 128, precision),
+                        "measured_over_algorithmic": round((read_b + write_b) / bmin_bytes(256 * 128 * 128, precision), 3),
                         "top_readers_KB_raw_per_iteration": {k: v for k, v in top}},
     "dominant_family": {"family": "conv_bwd_weight k3 s1",
                         "kernels": "conv_bwd_weight_mfma_kernel<3, 1, 8, 2, *> / conv_bwd_weight_mfma_pair_kernel<3, 1, 8, 2> / ..._merged_kernel (both orientations) and conv_bwd_weight_smallco_kernel",
@@ -85,6 +85,11 @@ def kernel_family(name):
     m = re.match(r"conv_q4i_mfma_kernel<\d+, \d+, (true|false)", name)               # <R, NB, FLIP, AL, KHP>
     if m:
         return "conv_bwd_data k3 s1" if m.group(1) == "true" else "conv_fwd k3 s1"
+    m = re.match(r"conv_bf16_kernel<3, \d+, \d+, (true|false)", name)                 # <KD, NR, NH, FLIP, NS, XB, YB> (bf16 / split modes)
+    if m:
+        return "conv_bwd_data k3 s1" if m.group(1) == "true" else "conv_fwd k3 s1"
+    if name.startswith("conv_bf16_bwd_weight_kernel"):
+        return "conv_bwd_weight k3 s1"
     if name.startswith("splitk_reduce_kernel"):
         return None                                                                   # serves forward and backward-data launches alike: left out
     return None
