@@ -21,6 +21,10 @@
 // epilogue (bias, BatchNorm {sum, sum^2} partials, gradient fan-in) are those of the fp32 kernel.
 #include "common.h"
 
+#include <map>
+#include <mutex>
+#include <tuple>
+
 void dpi_conv_out_dims(const dpi_conv_desc* d, int* Do, int* Ho, int* Wo);
 
 namespace {
@@ -40,8 +44,9 @@ struct BArgs {
   int D, H, W;
   int ntd, nth, ntw;
   long w_out_stride, w_in_stride;
+  const unsigned short* __restrict__ wpk;      // the weights as bf16 A fragments (conv_bf16_pack_kernel), written before this launch
   int accumulate;
-  int debug;     // tuning experiments only (dpi_set_bf16_debug): 1 skip the MFMA phase, 2 skip the global loads, 4 skip the LDS stores
+  int debug;     // tuning experiments only (dpi_set_bf16_debug): 1 skip the MFMA phase, 2 skip the global loads, 4 skip the LDS stores, 8 cache-hot loads
   int xb, yb;    // storage type of x / y in HBM: 1 = bf16 (dpi_conv_desc.io), 0 = fp32
   // second input through a 1x1x1 kernel at the OUTPUT positions (x2 != nullptr; backward-data launches only): y += W2 * x2 with
   // x2 [C2][D][H][W] of x's storage type and W2[co][c] = w2[co * w2_co_stride + c * w2_c_stride] — the input gradient of a 3x3x3 layer and the
@@ -54,7 +59,11 @@ struct BArgs {
   long w2_co_stride, w2_c_stride;
 };
 
-template <int KD, int NR, int NH>
+// WIDE (bf16 input tensors): the halo tile starts 4 columns left of the output tile and is 8 columns wider than it, so that every row is
+// a whole number of ALIGNED 4-element pieces (8 bytes of a bf16 tensor): one load instruction per piece instead of one per element.  The
+// kernel is bound by the NUMBER of staging loads, not their bytes (tools/bench_conv.py --bf16-debug: 25->16 forward 0.273 ms, 0.142 ms
+// without the global loads): 16 instead of 40 load instructions per thread and 8-channel group.
+template <int KD, int NR, int NH, bool WIDE = false>
 struct GeoB {
   static constexpr bool SLICES = (KD == 3 && NR >= 4);          // waves split depth; otherwise they split rows
   static constexpr int TZ = SLICES ? 4 : 1;                      // output tile
@@ -62,7 +71,11 @@ struct GeoB {
   static constexpr int TW = 16 * NH;
   static constexpr int ID = TZ - 1 + KD;                         // input (halo) tile, positions stored densely [ID][IH][IW]
   static constexpr int IH = TY + 2;
-  static constexpr int IW = TW + 2;
+  static constexpr int IW = WIDE ? TW + 8 : TW + 2;
+  static constexpr int COL0 = WIDE ? 4 : 1;                      // tile column of global column ow0
+  static constexpr int QW = IW / 4;                              // WIDE: 4-element pieces per row, pieces per tile, per thread
+  static constexpr int NQ = ID * IH * QW;
+  static constexpr int EQ = (NQ + 255) / 256;
   static constexpr int TILE = ID * IH * IW;
   static constexpr int E = (TILE + 255) / 256;
   static constexpr int TAPS = KD * 9;
@@ -108,11 +121,12 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, uns
 template <int KD, int NR, int NH, bool FLIP, int NS = 1, bool XB = false, bool YB = false>
 __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
   a.xb = XB; a.yb = YB;
-  using G = GeoB<KD, NR, NH>;
+  using G = GeoB<KD, NR, NH, XB>;
   constexpr int TAPS = G::TAPS, NTG = G::NTG, PD = (KD - 1) / 2, NT = NR * NH;
-  constexpr int XW = G::TILE * 4, WW = NTG * 64 * 8;                        // words / halfwords per operand copy
+  constexpr int WT = 128;                                                    // halfwords per tap of the A-fragment buffer: 16 co x 8 ci
+  constexpr int XW = G::TILE * 4, WW = NTG * 4 * WT;                        // words / halfwords per operand copy
   __shared__ __attribute__((aligned(16))) unsigned xl[NS * XW];             // [term][position][8 bf16]
-  __shared__ __attribute__((aligned(16))) unsigned short wl[NS * WW];       // [term][g][lane][8 bf16]: A fragments
+  __shared__ __attribute__((aligned(16))) unsigned short wl[NS * WW];       // [term][tap = 4 g + lane / 16][co = lane % 16][8 bf16]: A fragments
   __shared__ double red[4][16][2];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -134,15 +148,33 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
   const int wz = G::SLICES ? wid : 0, wh = G::SLICES ? 0 : wid * NR;
 
   // halo-tile slots of this thread: position idx = tid + 256 e  <->  (dz, hy, col), and the global voxel offset (or -1 = padding)
-  int goff[G::E];
+  static_assert(!XB || NS == 1, "bf16 tensors: bf16 arithmetic mode only");
+  int goff[XB ? 1 : G::E];
+  if constexpr (!XB)
 #pragma unroll
   for (int e = 0; e < G::E; ++e) {
     const int idx = tid + e * 256;
     const int col = idx % G::IW, row = idx / G::IW;
     const int hy = row % G::IH, dz = row / G::IH;
-    const int gd = od0 - PD + dz, gh = oh0 - 1 + hy, gw = ow0 - 1 + col;
+    const int gd = od0 - PD + dz, gh = oh0 - 1 + hy, gw = ow0 - G::COL0 + col;
     const bool ok = idx < G::TILE && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
     goff[e] = ok ? (gd * a.H + gh) * a.W + gw : -1;
+  }
+  // WIDE staging: this thread's 4-element pieces (piece qi = tid + 256 e <-> (dz, hy, q)): element offset of the piece or -1, and its first
+  // tile position.  Needs rows that are whole pieces (W % 4 == 0) and an 8-byte aligned tensor: dpi_conv_bf16_usable.
+  int qoff[XB ? G::EQ : 1], qpos[XB ? G::EQ : 1];
+  if constexpr (XB) {
+#pragma unroll
+    for (int e = 0; e < G::EQ; ++e) {
+      const int qi = tid + e * 256;
+      const int q = qi % G::QW, row = qi / G::QW;
+      const int hy = row % G::IH, dz = row / G::IH;
+      const int gd = od0 - PD + dz, gh = oh0 - 1 + hy, gw = ow0 - G::COL0 + 4 * q;
+      const bool ok = qi < G::NQ && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+      qoff[e] = ok ? (gd * a.H + gh) * a.W + gw : -1;
+      if (a.debug & 8) qoff[e] = (qi * 4) & 0x3fff;              // experiment: every tile reads the same 32 KB of each channel (cache hits)
+      qpos[e] = (dz * G::IH + hy) * G::IW + 4 * q;
+    }
   }
   // per-lane tap offsets (in positions) of the NTG tap groups; K slot lk of group g is tap 4 g + lk (clamped: its weights are 0)
   int toff[NTG];
@@ -152,38 +184,45 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
     const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
     toff[g] = (kd * G::IH + kh) * G::IW + kw;
   }
-  const int pbase = (wz * G::IH + wh) * G::IW + lj;            // position of output voxel (row 0, column block 0) at tap (0,0,0)
+  const int pbase = (wz * G::IH + wh) * G::IW + lj + (G::COL0 - 1);   // position of output voxel (row 0, column block 0) at tap (0,0,0)
 
-  float sr[8][G::E];                                           // next channel group, raw fp32, in flight
-  float wq[G::WE];                                             // next channel group's weights of this thread
+  float sr[XB ? 1 : 8][XB ? 1 : G::E];                         // next channel group, raw fp32, in flight
+  unsigned sq[XB ? 8 : 1][XB ? G::EQ : 1][2];                  // WIDE: the group's pieces, two raw dwords (four bf16) each
   auto load_x = [&](int c0) {
-    if (a.xb) {           // bf16 tensor: ONE uniform branch around the whole group; the raw 16 bits are kept, widened when staged (common.h)
+    if constexpr (XB) {   // bf16 tensor: the raw 16-bit halves are kept and transposed when staged
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const int ci = min(c0 + c, a.Cin - 1);
         const __amdgpu_buffer_rsrc_t r = dpi_buffer_t(dpi_at(a.x, (size_t)ci * V, true), V, true);
 #pragma unroll
-        for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_buffer_load_bf16_raw(r, goff[e]);
+        for (int e = 0; e < G::EQ; ++e) {
+          const dpi_u32x2v u = __builtin_bit_cast(dpi_u32x2v, __builtin_amdgcn_raw_buffer_load_b64(r, qoff[e] >= 0 ? qoff[e] * 2 : -8, 0, 0));
+          sq[c][e][0] = u.x; sq[c][e][1] = u.y;
+        }
       }
-      return;
-    }
+    } else {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int ci = min(c0 + c, a.Cin - 1);                   // channels past Cin: their weights are zero
-      const __amdgpu_buffer_rsrc_t r = dpi_buffer(a.x + (size_t)ci * V, V * sizeof(float));
+      for (int c = 0; c < 8; ++c) {
+        const int ci = min(c0 + c, a.Cin - 1);                   // channels past Cin: their weights are zero
+        const __amdgpu_buffer_rsrc_t r = dpi_buffer(a.x + (size_t)ci * V, V * sizeof(float));
 #pragma unroll
-      for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_buffer_load(r, goff[e] * 4);
+        for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_buffer_load(r, goff[e] * 4);
+      }
     }
   };
+  // Weights of a channel group: ready-made A fragments [term][tap = 4 g + lane / 16][co = lane % 16][8 ci] (conv_bf16_pack_kernel, one
+  // tiny launch in front of this one), 16 bytes per thread and load, coalesced, stored as they come.  Gathered from the fp32 weights in
+  // fragment order HERE, every lane of an instruction read its own cache line — 64 tag lookups for 256 bytes, 14 times per thread and
+  // group — and the L1 was the busiest unit of the CU: 25->16 forward 0.295 -> 0.208 ms with the lookups taken away; reading in memory
+  // order instead trades them for bank conflicts of the 2-byte staging writes (0.27 / 0.30 ms) (profiles/README.md, round 4).
+  constexpr int WV = NS * WW / 8, WPE = (WV + 255) / 256;      // 16-byte pieces of a group's fragments; per thread
+  u32x4 wq[WPE];                                               // next channel group's pieces of this thread
+  const u32x4* __restrict__ const wsrc = reinterpret_cast<const u32x4*>(a.wpk) + (size_t)blockIdx.y * ((a.Cin + 7) >> 3) * WV;
   auto load_w = [&](int c0) {
 #pragma unroll
-    for (int j = 0; j < G::WE; ++j) {
-      const int q = tid + j * 256;                             // element (g, lane64, i)
-      const int i = q & 7, l64 = (q >> 3) & 63, g = q >> 9;
-      const int co = n0 + (l64 & 15), tap = 4 * g + (l64 >> 4), ci = c0 + i;
-      const bool ok = q < NTG * 512 && co < a.Cout && ci < a.Cin && tap < TAPS;
-      const float v = a.w[(ok ? co : 0) * a.w_out_stride + (ok ? ci : 0) * a.w_in_stride + (ok ? (FLIP ? TAPS - 1 - tap : tap) : 0)];
-      wq[j] = ok ? v : 0.f;
+    for (int j = 0; j < WPE; ++j) {
+      const int i = tid + j * 256;
+      wq[j] = wsrc[(c0 >> 3) * WV + ((j + 1) * 256 <= WV || i < WV ? i : 0)];
     }
   };
   if (!(a.debug & 2)) { load_x(0); load_w(0); }
@@ -197,15 +236,50 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
   for (int c0 = 0; c0 < a.Cin; c0 += 8) {
     __syncthreads();                                           // everyone is done reading the previous group
     // registers -> LDS: chain (BN + LeakyReLU of the producer) on in-volume samples, round to bf16, 8 channels per position
-    if (!(a.debug & 4)) {
-      // a bf16 tensor without a chain in the bf16 arithmetic mode needs no conversion at all: two raw halves make one packed dword
-      const bool rawpack = NS == 1 && a.xb && !a.chain;
-      if (a.xb && !rawpack) {
+    if constexpr (XB) {
+      if (!(a.debug & 4)) {
+        // 4 positions x 8 channels per piece: position j of the piece takes half (j & 1) of dword (j >> 1) of every channel; its 16 bytes
+        // in the operand buffer are the 8 channels' halves, two per dword — a 4 x 8 transposition of 16-bit values in registers
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+        for (int e = 0; e < G::EQ; ++e) {
+          const int qi = tid + e * 256;
+          if ((e + 1) * 256 <= G::NQ || qi < G::NQ) {
+            if (a.chain == nullptr) {
 #pragma unroll
-          for (int e = 0; e < G::E; ++e) sr[c][e] = dpi_widen_raw(sr[c][e]);
+              for (int j = 0; j < 4; ++j) {
+                unsigned o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  // v_perm_b32: bytes 0-3 of the selector index the second source, 4-7 the first
+                  o[k] = __builtin_amdgcn_perm(sq[2 * k + 1][e][j >> 1], sq[2 * k][e][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
+                }
+                *reinterpret_cast<u32x4*>(xl + (qpos[e] + j) * 4) = (u32x4){o[0], o[1], o[2], o[3]};
+
+              }
+            } else {
+              unsigned o[4][4];                                                   // [position][channel pair]
+              const bool in = qoff[e] >= 0;                                       // zero padding stays zero
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const Chain ch0 = load_chain(a.chain, min(c0 + 2 * k, a.Cin - 1)), ch1 = load_chain(a.chain, min(c0 + 2 * k + 1, a.Cin - 1));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const unsigned u0 = sq[2 * k][e][j >> 1], u1 = sq[2 * k + 1][e][j >> 1];
+                  const float x0 = __builtin_bit_cast(float, (j & 1) ? (u0 & 0xffff0000u) : (u0 << 16));
+                  const float x1 = __builtin_bit_cast(float, (j & 1) ? (u1 & 0xffff0000u) : (u1 << 16));
+                  o[j][k] = pack_bf16(in ? apply_chain(ch0, x0) : x0, in ? apply_chain(ch1, x1) : x1);
+                }
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(xl + (qpos[e] + j) * 4) = (u32x4){o[j][0], o[j][1], o[j][2], o[j][3]};
+
+            }
+          }
+        }
       }
+    }
+    if (!(a.debug & 4)) {
+      if constexpr (!XB) {
       if (a.chain) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -219,13 +293,8 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
         const int idx = tid + e * 256;
         if ((e + 1) * 256 <= G::TILE || idx < G::TILE) {
           if constexpr (NS == 1) {
-            if (rawpack) {
-              auto pr = [](float lo, float hi) { return __builtin_bit_cast(unsigned, lo) | (__builtin_bit_cast(unsigned, hi) << 16); };
-              *reinterpret_cast<u32x4*>(xl + idx * 4) = (u32x4){pr(sr[0][e], sr[1][e]), pr(sr[2][e], sr[3][e]), pr(sr[4][e], sr[5][e]), pr(sr[6][e], sr[7][e])};
-            } else {
-              *reinterpret_cast<u32x4*>(xl + idx * 4) = (u32x4){pack_bf16(sr[0][e], sr[1][e]), pack_bf16(sr[2][e], sr[3][e]),
-                                                                pack_bf16(sr[4][e], sr[5][e]), pack_bf16(sr[6][e], sr[7][e])};
-            }
+            *reinterpret_cast<u32x4*>(xl + idx * 4) = (u32x4){pack_bf16(sr[0][e], sr[1][e]), pack_bf16(sr[2][e], sr[3][e]),
+                                                              pack_bf16(sr[4][e], sr[5][e]), pack_bf16(sr[6][e], sr[7][e])};
           } else {
             unsigned h[4], m[4], l[4];
 #pragma unroll
@@ -236,17 +305,11 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
           }
         }
       }
+      }
 #pragma unroll
-      for (int j = 0; j < G::WE; ++j) {
-        const int q = tid + j * 256;
-        if ((j + 1) * 256 <= NTG * 512 || q < NTG * 512) {
-          if constexpr (NS == 1) wl[q] = (unsigned short)bf16_bits(wq[j]);
-          else {
-            unsigned h, m, l;
-            split3(wq[j], h, m, l);
-            wl[q] = (unsigned short)h; wl[WW + q] = (unsigned short)m; wl[2 * WW + q] = (unsigned short)l;
-          }
-        }
+      for (int j = 0; j < WPE; ++j) {
+        const int i = tid + j * 256;
+        if ((j + 1) * 256 <= WV || i < WV) *reinterpret_cast<u32x4*>(wl + i * 8) = wq[j];
       }
     }
     __syncthreads();
@@ -257,20 +320,24 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
     for (int g = 0; g < NTG; ++g) {
       // the A fragment of this tap group only lives across its NT MFMAs (7 resident fragments cost 28 registers = the
       // third wave per SIMD)
-      auto frag_w = [&](int term) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wl + term * WW + (g * 64 + lane) * 8)); };
+      auto frag_w = [&](int term) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wl + term * WW + (4 * g + lk) * WT + lj * 8)); };
       auto frag_x = [&](int term, int p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xl + term * XW + p * 4)); };
+      // the tap group's base position is made opaque HERE: left to itself the compiler hoists all NTG * NT loop-invariant fragment addresses
+      // out of the channel loop (56 registers, spilled) instead of one base per group + the instruction's immediate offset
+      int pg = pbase + toff[g];
+      asm volatile("" : "+v"(pg));
       if constexpr (NS == 1) {
         const bf16x8 af = frag_w(0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {                         // consecutive MFMAs go to different accumulators
-          const int p = pbase + toff[g] + (t / NH) * G::IW + (t % NH) * 16;
+          const int p = pg + (t / NH) * G::IW + (t % NH) * 16;
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_x(0, p), acc[t], 0, 0, 0);
         }
       } else {
         const bf16x8 wh = frag_w(0), wm = frag_w(1), wlo = frag_w(2);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const int p = pbase + toff[g] + (t / NH) * G::IW + (t % NH) * 16;
+          const int p = pg + (t / NH) * G::IW + (t % NH) * 16;
           const bf16x8 xh = frag_x(0, p), xm = frag_x(1, p), xlo = frag_x(2, p);
           // smallest terms first: l*h, h*l (2^-16), m*m (2^-16), h*m, m*h (2^-8), h*h
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh, acc[t], 0, 0, 0);
@@ -289,23 +356,41 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
     // lk < 2 multiplies plane lk (K = 32 with 16 real channels: the A fragments of slots 2, 3 are zero, their B reads repeat planes 0, 1)
     constexpr int NPOS = G::TZ * G::TY * G::TW, E2 = (NPOS + 255) / 256;
     static_assert(2 * NPOS <= G::TILE, "the second input reuses the halo-tile buffer");
-    int g2[E2];
+    // bf16 tensors: 4-element pieces as above — the pieces of plane (qi / NQ2) are (qi % NQ2) <-> (dz, hy, q); 8 loads of 8 bytes per piece
+    constexpr int NQ2 = NPOS / 4, EQ2 = (2 * NQ2 + 255) / 256;
+    int g2[XB ? EQ2 : E2];
+    if constexpr (XB) {
 #pragma unroll
-    for (int e = 0; e < E2; ++e) {
-      const int idx = tid + e * 256;
-      const int col = idx % G::TW, row = idx / G::TW;
-      const int hy = row % G::TY, dz = row / G::TY;
-      const int od = od0 + dz, oh = oh0 + hy, ow = ow0 + col;
-      g2[e] = (idx < NPOS && od < Do && oh < Ho && ow < Wo) ? (od * Ho + oh) * Wo + ow : -1;
+      for (int e = 0; e < EQ2; ++e) {
+        const int qi = (tid + e * 256) % NQ2;
+        const int q = qi % (G::TW / 4), row = qi / (G::TW / 4);
+        const int hy = row % G::TY, dz = row / G::TY;
+        const int od = od0 + dz, oh = oh0 + hy, ow = ow0 + 4 * q;
+        g2[e] = (tid + e * 256 < 2 * NQ2 && od < Do && oh < Ho && ow < Wo) ? (od * Ho + oh) * Wo + ow : -1;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < E2; ++e) {
+        const int idx = tid + e * 256;
+        const int col = idx % G::TW, row = idx / G::TW;
+        const int hy = row % G::TY, dz = row / G::TY;
+        const int od = od0 + dz, oh = oh0 + hy, ow = ow0 + col;
+        g2[e] = (idx < NPOS && od < Do && oh < Ho && ow < Wo) ? (od * Ho + oh) * Wo + ow : -1;
+      }
     }
     for (int c0 = 0; c0 < a.C2; c0 += 16) {
-      float s2[16][E2], w2q[2];
-      if (XB) {
+      float s2[XB ? 1 : 16][XB ? 1 : E2], w2q[2];
+      unsigned q2[XB ? 8 : 1][XB ? EQ2 : 1][2];
+      if constexpr (XB) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const __amdgpu_buffer_rsrc_t r = dpi_buffer_t(dpi_at(a.x2, (size_t)min(c0 + c, a.C2 - 1) * Vo, true), Vo, true);
+        for (int e = 0; e < EQ2; ++e) {
+          const int plane = (tid + e * 256) / NQ2;
 #pragma unroll
-          for (int e = 0; e < E2; ++e) s2[c][e] = dpi_buffer_load_bf16_raw(r, g2[e]);
+          for (int c = 0; c < 8; ++c) {
+            const __amdgpu_buffer_rsrc_t r = dpi_buffer_t(dpi_at(a.x2, (size_t)min(c0 + 8 * plane + c, a.C2 - 1) * Vo, true), Vo, true);
+            const dpi_u32x2v u = __builtin_bit_cast(dpi_u32x2v, __builtin_amdgcn_raw_buffer_load_b64(r, g2[e] >= 0 ? g2[e] * 2 : -8, 0, 0));
+            q2[c][e][0] = u.x; q2[c][e][1] = u.y;
+          }
         }
       } else {
 #pragma unroll
@@ -325,20 +410,29 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
         w2q[j] = ok ? v : 0.f;
       }
       __syncthreads();                                           // the main loop's last group (or the previous step) has been read
+      if constexpr (XB) {
 #pragma unroll
-      for (int e = 0; e < E2; ++e) {
-        const int idx = tid + e * 256;
-        if ((e + 1) * 256 <= NPOS || idx < NPOS) {
+        for (int e = 0; e < EQ2; ++e) {
+          const int qi = tid + e * 256;
+          if ((e + 1) * 256 <= 2 * NQ2 || qi < 2 * NQ2) {
 #pragma unroll
-          for (int g = 0; g < 2; ++g) {
-            if (XB) {
-              auto pr = [](float lo, float hi) { return __builtin_bit_cast(unsigned, lo) | (__builtin_bit_cast(unsigned, hi) << 16); };
-              *reinterpret_cast<u32x4*>(xl + (g * NPOS + idx) * 4) = (u32x4){pr(s2[8 * g][e], s2[8 * g + 1][e]), pr(s2[8 * g + 2][e], s2[8 * g + 3][e]),
-                                                                             pr(s2[8 * g + 4][e], s2[8 * g + 5][e]), pr(s2[8 * g + 6][e], s2[8 * g + 7][e])};
-            } else {
+            for (int j = 0; j < 4; ++j) {
+              unsigned o[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) o[k] = __builtin_amdgcn_perm(q2[2 * k + 1][e][j >> 1], q2[2 * k][e][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
+              *reinterpret_cast<u32x4*>(xl + (4 * qi + j) * 4) = (u32x4){o[0], o[1], o[2], o[3]};     // plane * NPOS + 4 * piece + j
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < E2; ++e) {
+          const int idx = tid + e * 256;
+          if ((e + 1) * 256 <= NPOS || idx < NPOS) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
               *reinterpret_cast<u32x4*>(xl + (g * NPOS + idx) * 4) = (u32x4){pack_bf16(s2[8 * g][e], s2[8 * g + 1][e]), pack_bf16(s2[8 * g + 2][e], s2[8 * g + 3][e]),
                                                                              pack_bf16(s2[8 * g + 4][e], s2[8 * g + 5][e]), pack_bf16(s2[8 * g + 6][e], s2[8 * g + 7][e])};
-            }
           }
         }
       }
@@ -429,7 +523,62 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
   }
 }
 
+// The layer's weights as A fragments: block (group, co block) writes [term][tap 4 NTG][co 16][ci 8] bf16 — rounded (NS = 1) or split into
+// three bf16 terms (NS = 3), taps flipped for backward-data, zeros for channels / taps past the end.  One launch in front of every
+// conv_bf16_kernel launch, on its stream: a few microseconds over <= 1 MB, instead of the same gather by every tile of the main kernel.
+template <int KD, bool FLIP, int NS>
+__global__ __launch_bounds__(256) void conv_bf16_pack_kernel(const float* __restrict__ w, long w_out_stride, long w_in_stride, int Cin, int Cout,
+                                                             unsigned short* __restrict__ out) {
+  constexpr int TAPS = KD * 9, NTG = (TAPS + 3) / 4, WW = NTG * 512;
+  unsigned short* __restrict__ const o = out + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NS * WW;
+  for (int q = threadIdx.x; q < WW; q += 256) {
+    const int ci = blockIdx.x * 8 + (q & 7), co = blockIdx.y * 16 + ((q >> 3) & 15), tap = q >> 7;
+    const bool ok = co < Cout && ci < Cin && tap < TAPS;
+    const float v = ok ? w[co * w_out_stride + ci * w_in_stride + (FLIP ? TAPS - 1 - tap : tap)] : 0.f;
+    if constexpr (NS == 1) o[q] = (unsigned short)bf16_bits(v);
+    else {
+      unsigned h, m, l;
+      split3(v, h, m, l);
+      o[q] = (unsigned short)h; o[WW + q] = (unsigned short)m; o[2 * WW + q] = (unsigned short)l;
+    }
+  }
+}
+
 }  // namespace
+
+// Packed-weight scratch: one slot per (weight tensor, direction, shape), carved from 64 MB chunks and kept for the life of the process.
+// Every launch re-packs into its layer's slot, on the launch's stream, so the slot always holds what the main kernel behind it reads;
+// two launches of the SAME layer on different streams write identical bytes.  Keyed by stream instead, a graph capture (which runs on a
+// stream of its own) would need its region allocated during the capture, and two graphs captured on one stream would share one.
+// A layer first seen during a capture takes its slot from a chunk that already exists (hipMalloc is not capturable): run one eager
+// iteration first, as for every captured workload here.
+static constexpr size_t kPackChunk = 64u << 20, kPackMaxSlot = 16u << 20;
+static std::mutex g_pack_mutex;
+static std::map<std::tuple<const void*, int, int, int, int>, unsigned short*> g_pack_slots;
+static char* g_pack_chunk = nullptr;
+static size_t g_pack_used = kPackChunk;
+static size_t bf16_pack_bytes(int kd, int cin, int cout, int ns) { return (size_t)cdiv(cout, 16) * cdiv(cin, 8) * ns * ((kd * 9 + 3) / 4) * 512 * sizeof(unsigned short); }
+static unsigned short* bf16_pack_slot(const void* w, int kd, int cin, int cout, bool flip, int ns) {
+  std::lock_guard<std::mutex> lock(g_pack_mutex);
+  const auto key = std::make_tuple(w, kd, cin, cout, (flip ? 1 : 0) | (ns << 1));
+  const auto it = g_pack_slots.find(key);
+  if (it != g_pack_slots.end()) return it->second;
+  const size_t bytes = (bf16_pack_bytes(kd, cin, cout, ns) + 255) & ~(size_t)255;
+  if (g_pack_used + bytes > kPackChunk) {
+    void* p = nullptr;
+    if (hipMalloc(&p, kPackChunk) != hipSuccess) {
+      (void)hipGetLastError();
+      dpi_set_error("conv_bf16_mfma: cannot allocate packed-weight scratch (a layer's first launch inside a graph capture? run one eager iteration first)");
+      return nullptr;
+    }
+    g_pack_chunk = static_cast<char*>(p);
+    g_pack_used = 0;
+  }
+  unsigned short* const slot = reinterpret_cast<unsigned short*>(g_pack_chunk + g_pack_used);
+  g_pack_used += bytes;
+  g_pack_slots.emplace(key, slot);
+  return slot;
+}
 
 // tile variant: the 4x4x32 tile (2-D: 1x16x32) while it still gives >= 512 workgroups, else row-band tiles of one depth slice.
 // (The 4x8x32 tile of the fp32 kernel needs 64 prefetch + 64 accumulator registers here and spills.)
@@ -452,7 +601,7 @@ static int bf16_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth
 static int g_bf16_debug = 0;
 static int g_bf16_all = 0;      // 1: every 3x3(x3) stride-1 convolution (tests); 0: only where the kernel beats the fp32 one
 bool dpi_bf16_force_all() { return g_bf16_all != 0; }
-extern "C" void dpi_set_bf16_debug(int flags) { g_bf16_debug = flags & 7; g_bf16_all = (flags >> 3) & 1; g_split_nh = (flags & 16) ? 1 : 2; g_bf16_nh = (flags & 32) ? 1 : 2; }
+extern "C" void dpi_set_bf16_debug(int flags) { g_bf16_debug = (flags & 7) | ((flags & 64) ? 8 : 0); g_bf16_all = (flags >> 3) & 1; g_split_nh = (flags & 16) ? 1 : 2; g_bf16_nh = (flags & 32) ? 1 : 2; }
 
 // Where the mode applies (measured in the iteration, profiles/r02_bf16_kernel_stats_layers.txt): the big-tile variant — full
 // resolution and the first coarse level — is 1.2-2.1x faster than the fp32 kernels except for 4 input channels (one half-empty K
@@ -474,6 +623,8 @@ static bool bf16_pays(const dpi_conv_desc* d, bool flip) {
 
 bool dpi_conv_bf16_usable(const dpi_conv_desc* d, bool flip) {
   if (d->precision == 2 && (dpi_io_in(d, flip) || dpi_io_out(d, flip))) return false;      // the split instantiations are compiled for fp32 tensors
+  if (bf16_pack_bytes(d->kd, d->Cin, d->Cout, d->precision == 2 ? 3 : 1) > kPackMaxSlot) return false;
+  if (dpi_io_in(d, flip) && (d->W & 3)) return false;      // bf16 input: staged in aligned 4-element pieces of a row (GeoB WIDE); else conv_mfma
   return d->precision >= 1 && d->k == 3 && d->stride == 1 && bf16_pays(d, flip);
 }
 
@@ -510,8 +661,21 @@ int dpi_conv_bf16_run(const dpi_conv_desc* d, const float* x, const float* chain
   const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
   int nr, nh;
   bf16_variant(d, cout, &nr, &nh);
-  BArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, accumulate, g_bf16_debug,
+  unsigned short* const wpk = bf16_pack_slot(w, d->kd, cin, cout, flip, d->precision == 2 ? 3 : 1);
+  if (!wpk) return DPI_E_LAUNCH;
+  {
+    const dim3 pg(cdiv(cin, 8), cdiv(cout, 16));
+    if (d->precision == 2) {
+      if (d->kd == 3) { if (flip) conv_bf16_pack_kernel<3, true, 3><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk); else conv_bf16_pack_kernel<3, false, 3><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk); }
+      else { if (flip) conv_bf16_pack_kernel<1, true, 3><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk); else conv_bf16_pack_kernel<1, false, 3><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk); }
+    } else {
+      if (d->kd == 3) { if (flip) conv_bf16_pack_kernel<3, true, 1><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk); else conv_bf16_pack_kernel<3, false, 1><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk); }
+      else { if (flip) conv_bf16_pack_kernel<1, true, 1><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk); else conv_bf16_pack_kernel<1, false, 1><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk); }
+    }
+  }
+  BArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, wpk, accumulate, g_bf16_debug,
           dpi_io_in(d, flip), dpi_io_out(d, flip), nullptr, nullptr, 0, 0, 0};
+  if (a.xb && (((uintptr_t)x & 7) || (sec && ((uintptr_t)sec->x2 & 7)))) { dpi_set_error("conv_bf16_mfma: a bf16 input tensor must be 8-byte aligned"); return DPI_E_ARG; }
   if (sec) { a.x2 = sec->x2; a.w2 = sec->w2; a.C2 = sec->C2; a.w2_co_stride = sec->w2_co_stride; a.w2_c_stride = sec->w2_c_stride; }
   const int ntiles = bf16_tiles(d, nr, nh, &a.ntd, &a.nth, &a.ntw);
   dim3 grid(ntiles, cdiv(cout, 16));
