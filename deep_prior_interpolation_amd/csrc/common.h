@@ -8,6 +8,9 @@
 #define DPI_WAVE 64
 
 void dpi_set_error(const char* fmt, ...);
+// packed-weight scratch (conv_bf16_mfma.hip): the slot of one (weight tensor, shape, tag), allocated at its first use; nullptr + error text on failure
+void* dpi_pack_slot(const void* w, int kd, int cin, int cout, int tag, size_t nbytes);
+size_t dpi_pack_max_slot();
 int dpi_check_launch(const char* what);
 // Validates a caller's descriptor (size field first: a binding built against another struct layout is rejected, not read past).
 int dpi_check_conv_desc(const dpi_conv_desc* d);

@@ -119,7 +119,7 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, uns
 // XB / YB: storage type of x / y (true = bf16) as TEMPLATE parameters: as run-time flags they cost the fp32-tensor instantiation 10 % (and the
 // storage mode as much), measured in the iteration (profiles/README.md, round 4).
 template <int KD, int NR, int NH, bool FLIP, int NS = 1, bool XB = false, bool YB = false>
-__global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BArgs a) {
+__global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_bf16_kernel(BArgs a) {
   a.xb = XB; a.yb = YB;
   using G = GeoB<KD, NR, NH, XB>;
   constexpr int TAPS = G::TAPS, NTG = G::NTG, PD = (KD - 1) / 2, NT = NR * NH;
@@ -546,39 +546,41 @@ __global__ __launch_bounds__(256) void conv_bf16_pack_kernel(const float* __rest
 
 }  // namespace
 
-// Packed-weight scratch: one slot per (weight tensor, direction, shape), carved from 64 MB chunks and kept for the life of the process.
-// Every launch re-packs into its layer's slot, on the launch's stream, so the slot always holds what the main kernel behind it reads;
-// two launches of the SAME layer on different streams write identical bytes.  Keyed by stream instead, a graph capture (which runs on a
-// stream of its own) would need its region allocated during the capture, and two graphs captured on one stream would share one.
+// Packed-weight scratch: one slot per (weight tensor, direction, shape, kernel family), carved from 64 MB chunks and kept for the life of
+// the process.  Every launch re-packs into its layer's slot, on the launch's stream, so the slot always holds what the main kernel behind
+// it reads; two launches of the SAME layer on different streams write identical bytes.  Keyed by stream instead, a graph capture (which
+// runs on a stream of its own) would need its region allocated during the capture, and two graphs captured on one stream would share one.
 // A layer first seen during a capture takes its slot from a chunk that already exists (hipMalloc is not capturable): run one eager
 // iteration first, as for every captured workload here.
 static constexpr size_t kPackChunk = 64u << 20, kPackMaxSlot = 16u << 20;
 static std::mutex g_pack_mutex;
-static std::map<std::tuple<const void*, int, int, int, int>, unsigned short*> g_pack_slots;
+static std::map<std::tuple<const void*, int, int, int, int>, void*> g_pack_slots;
 static char* g_pack_chunk = nullptr;
 static size_t g_pack_used = kPackChunk;
-static size_t bf16_pack_bytes(int kd, int cin, int cout, int ns) { return (size_t)cdiv(cout, 16) * cdiv(cin, 8) * ns * ((kd * 9 + 3) / 4) * 512 * sizeof(unsigned short); }
-static unsigned short* bf16_pack_slot(const void* w, int kd, int cin, int cout, bool flip, int ns) {
+size_t dpi_pack_max_slot() { return kPackMaxSlot; }
+void* dpi_pack_slot(const void* w, int kd, int cin, int cout, int tag, size_t nbytes) {
   std::lock_guard<std::mutex> lock(g_pack_mutex);
-  const auto key = std::make_tuple(w, kd, cin, cout, (flip ? 1 : 0) | (ns << 1));
+  const auto key = std::make_tuple(w, kd, cin, cout, tag);
   const auto it = g_pack_slots.find(key);
   if (it != g_pack_slots.end()) return it->second;
-  const size_t bytes = (bf16_pack_bytes(kd, cin, cout, ns) + 255) & ~(size_t)255;
+  const size_t bytes = (nbytes + 255) & ~(size_t)255;
+  if (bytes > kPackChunk) { dpi_set_error("packed-weight scratch: %zu bytes in one slot", bytes); return nullptr; }
   if (g_pack_used + bytes > kPackChunk) {
     void* p = nullptr;
     if (hipMalloc(&p, kPackChunk) != hipSuccess) {
       (void)hipGetLastError();
-      dpi_set_error("conv_bf16_mfma: cannot allocate packed-weight scratch (a layer's first launch inside a graph capture? run one eager iteration first)");
+      dpi_set_error("cannot allocate packed-weight scratch (a layer's first launch inside a graph capture? run one eager iteration first)");
       return nullptr;
     }
     g_pack_chunk = static_cast<char*>(p);
     g_pack_used = 0;
   }
-  unsigned short* const slot = reinterpret_cast<unsigned short*>(g_pack_chunk + g_pack_used);
+  void* const slot = g_pack_chunk + g_pack_used;
   g_pack_used += bytes;
   g_pack_slots.emplace(key, slot);
   return slot;
 }
+static size_t bf16_pack_bytes(int kd, int cin, int cout, int ns) { return (size_t)cdiv(cout, 16) * cdiv(cin, 8) * ns * ((kd * 9 + 3) / 4) * 512 * sizeof(unsigned short); }
 
 // tile variant: the 4x4x32 tile (2-D: 1x16x32) while it still gives >= 512 workgroups, else row-band tiles of one depth slice.
 // (The 4x8x32 tile of the fp32 kernel needs 64 prefetch + 64 accumulator registers here and spills.)
@@ -605,8 +607,8 @@ extern "C" void dpi_set_bf16_debug(int flags) { g_bf16_debug = (flags & 7) | ((f
 
 // Where the mode applies (measured in the iteration, profiles/r02_bf16_kernel_stats_layers.txt): the big-tile variant — full
 // resolution and the first coarse level — is 1.2-2.1x faster than the fp32 kernels except for 4 input channels (one half-empty K
-// block per tile); the row-band variants of the coarse levels (hundreds of channels = tens of 8-channel groups, two barriers and
-// one exposed load latency each, few tiles) are slower than the fp32 kernels and keep fp32 arithmetic.
+// block per tile).  The row-band variants of the coarse levels (hundreds of channels = tens of 8-channel groups, few tiles) were slower
+// than the fp32 kernels while every tile gathered its own weights; with the packed weights they win (round 4, below).
 static bool bf16_pays(const dpi_conv_desc* d, bool flip) {
   if (g_bf16_all) return true;
   const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
@@ -614,11 +616,14 @@ static bool bf16_pays(const dpi_conv_desc* d, bool flip) {
   bf16_variant(d, cout, &nr, &nh);
   // bf16 STORAGE (a tensor of this launch is bf16): every big-tile shape — the 4x4x1 kernel that serves the few-channel layers in fp32
   // does not take bf16 tensors, and half the staged bytes move the break-even of this (load-bound) kernel
-  if (d->precision == 1 && nr == 4 && (dpi_io_in(d, flip) || dpi_io_out(d, flip))) return true;
+  if (d->precision == 1 && (dpi_io_in(d, flip) || dpi_io_out(d, flip))) return true;
   // split mode (six MFMAs and three LDS fragments per position): wins 12-48 % over the fp32 kernels when both channel counts are
   // >= 8 (25<->16, 51<->32, 137<->8, 8<->13), loses with <= 4 channels on either side (64->4: 1.28 vs 0.96 ms)
   if (d->precision == 2) return nr == 4 && cin >= 8 && cout >= 8;
-  return nr == 4 && (cin > 4 || cout > 16);      // 4 -> 8 forward: 217 vs 196 us (fp32); 4 -> 67 (backward-data of 67 -> 4): 888 vs 1056 us
+  // the row-band variants of the coarse levels: 2-3.5x faster than the fp32 kernels since the weights come pre-packed (51->17 at 64x32x32
+  // 0.066 -> 0.026 ms, 212->128 at 32x16x16 0.130 -> 0.042, 276->17 0.279 -> 0.076; level with them only at 16x8x8)
+  if (nr != 4) return true;
+  return cin > 4 || cout > 16;      // 4 -> 8 forward: 217 vs 196 us (fp32); 4 -> 67 (backward-data of 67 -> 4): 888 vs 1056 us
 }
 
 bool dpi_conv_bf16_usable(const dpi_conv_desc* d, bool flip) {
@@ -661,7 +666,8 @@ int dpi_conv_bf16_run(const dpi_conv_desc* d, const float* x, const float* chain
   const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
   int nr, nh;
   bf16_variant(d, cout, &nr, &nh);
-  unsigned short* const wpk = bf16_pack_slot(w, d->kd, cin, cout, flip, d->precision == 2 ? 3 : 1);
+  const int ns = d->precision == 2 ? 3 : 1;
+  unsigned short* const wpk = static_cast<unsigned short*>(dpi_pack_slot(w, d->kd, cin, cout, (flip ? 1 : 0) | (ns << 1), bf16_pack_bytes(d->kd, cin, cout, ns)));
   if (!wpk) return DPI_E_LAUNCH;
   {
     const dim3 pg(cdiv(cin, 8), cdiv(cout, 16));
