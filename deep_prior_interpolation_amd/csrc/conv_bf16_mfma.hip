@@ -118,20 +118,23 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, uns
 
 // XB / YB: storage type of x / y (true = bf16) as TEMPLATE parameters: as run-time flags they cost the fp32-tensor instantiation 10 % (and the
 // storage mode as much), measured in the iteration (profiles/README.md, round 4).
-template <int KD, int NR, int NH, bool FLIP, int NS = 1, bool XB = false, bool YB = false>
-__global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_bf16_kernel(BArgs a) {
+// MT: 16-channel output tiles per workgroup (2 when the layer has more than 16 output channels): every staged tile and every B fragment
+// read from LDS — one per MFMA, the busiest unit of the MFMA phase — then feeds MT MFMAs.
+template <int KD, int NR, int NH, bool FLIP, int NS = 1, bool XB = false, bool YB = false, int MT = 1>
+__global__ __launch_bounds__(256, NS != 1 ? 2 : MT == 2 ? 3 : 4) void conv_bf16_kernel(BArgs a) {
+  static_assert(MT == 1 || NS == 1, "two output tiles: bf16 arithmetic mode only");
   a.xb = XB; a.yb = YB;
   using G = GeoB<KD, NR, NH, XB>;
   constexpr int TAPS = G::TAPS, NTG = G::NTG, PD = (KD - 1) / 2, NT = NR * NH;
   constexpr int WT = 128;                                                    // halfwords per tap of the A-fragment buffer: 16 co x 8 ci
   constexpr int XW = G::TILE * 4, WW = NTG * 4 * WT;                        // words / halfwords per operand copy
   __shared__ __attribute__((aligned(16))) unsigned xl[NS * XW];             // [term][position][8 bf16]
-  __shared__ __attribute__((aligned(16))) unsigned short wl[NS * WW];       // [term][tap = 4 g + lane / 16][co = lane % 16][8 bf16]: A fragments
-  __shared__ double red[4][16][2];
+  __shared__ __attribute__((aligned(16))) unsigned short wl[MT * NS * WW];  // [tile | term][tap = 4 g + lane / 16][co = lane % 16][8 bf16]: A fragments
+  __shared__ double red[4][16 * MT][2];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lk = lane >> 4, lj = lane & 15;
-  const int n0 = blockIdx.y * 16;
+  const int n0 = blockIdx.y * 16 * MT;
   const size_t V = (size_t)a.D * a.H * a.W;
   const int ntiles = a.ntd * a.nth * a.ntw;
   const int Do = a.D, Ho = a.H, Wo = a.W;                      // stride 1, 'same' padding
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_bf16_kernel(BArgs a
   // fragment order HERE, every lane of an instruction read its own cache line — 64 tag lookups for 256 bytes, 14 times per thread and
   // group — and the L1 was the busiest unit of the CU: 25->16 forward 0.295 -> 0.208 ms with the lookups taken away; reading in memory
   // order instead trades them for bank conflicts of the 2-byte staging writes (0.27 / 0.30 ms) (profiles/README.md, round 4).
-  constexpr int WV = NS * WW / 8, WPE = (WV + 255) / 256;      // 16-byte pieces of a group's fragments; per thread
+  constexpr int WV = MT * NS * WW / 8, WPE = (WV + 255) / 256; // 16-byte pieces of a group's fragments; per thread
   u32x4 wq[WPE];                                               // next channel group's pieces of this thread
   const u32x4* __restrict__ const wsrc = reinterpret_cast<const u32x4*>(a.wpk) + (size_t)blockIdx.y * ((a.Cin + 7) >> 3) * WV;
   auto load_w = [&](int c0) {
@@ -227,9 +230,11 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_bf16_kernel(BArgs a
   };
   if (!(a.debug & 2)) { load_x(0); load_w(0); }
 
-  f32x4 acc[NT];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // (gradient fan-in — accumulate — reads the destination in the EPILOGUE: loads left pending on the accumulator registers here put an
   //  s_waitcnt vmcnt(0) in front of the first MFMA, i.e. behind the whole first prefetch; measured on the Block3d fan-in launches)
 
@@ -327,11 +332,15 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_bf16_kernel(BArgs a
       int pg = pbase + toff[g];
       asm volatile("" : "+v"(pg));
       if constexpr (NS == 1) {
-        const bf16x8 af = frag_w(0);
+        bf16x8 af[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = frag_w(m);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {                         // consecutive MFMAs go to different accumulators
           const int p = pg + (t / NH) * G::IW + (t % NH) * 16;
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_x(0, p), acc[t], 0, 0, 0);
+          const bf16x8 xf = frag_x(0, p);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], xf, acc[m][t], 0, 0, 0);
         }
       } else {
         const bf16x8 wh = frag_w(0), wm = frag_w(1), wlo = frag_w(2);
@@ -340,12 +349,12 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_bf16_kernel(BArgs a
           const int p = pg + (t / NH) * G::IW + (t % NH) * 16;
           const bf16x8 xh = frag_x(0, p), xm = frag_x(1, p), xlo = frag_x(2, p);
           // smallest terms first: l*h, h*l (2^-16), m*m (2^-16), h*m, m*h (2^-8), h*h
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xlo, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[t], 0, 0, 0);
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh, acc[0][t], 0, 0, 0);
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xlo, acc[0][t], 0, 0, 0);
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, acc[0][t], 0, 0, 0);
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, acc[0][t], 0, 0, 0);
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, acc[0][t], 0, 0, 0);
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[0][t], 0, 0, 0);
         }
       }
     }
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_bf16_kernel(BArgs a
       }
     }
     for (int c0 = 0; c0 < a.C2; c0 += 16) {
-      float s2[XB ? 1 : 16][XB ? 1 : E2], w2q[2];
+      float s2[XB ? 1 : 16][XB ? 1 : E2], w2q[2 * MT];
       unsigned q2[XB ? 8 : 1][XB ? EQ2 : 1][2];
       if constexpr (XB) {
 #pragma unroll
@@ -401,10 +410,10 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_bf16_kernel(BArgs a
         }
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int q = tid + j * 256;                             // A fragment element (lane64 = q >> 3, i = q & 7)
+      for (int j = 0; j < 2 * MT; ++j) {
+        const int q = tid + (j & 1) * 256;                       // A fragment element (lane64 = q >> 3, i = q & 7) of output tile j / 2
         const int i = q & 7, l64 = q >> 3;
-        const int co = n0 + (l64 & 15), c = c0 + 8 * (l64 >> 4) + i;
+        const int co = n0 + 16 * (j >> 1) + (l64 & 15), c = c0 + 8 * (l64 >> 4) + i;
         const bool ok = (l64 >> 4) < 2 && co < a.Cout && c < a.C2;
         const float v = a.w2[(ok ? co : 0) * a.w2_co_stride + (ok ? c : 0) * a.w2_c_stride];
         w2q[j] = ok ? v : 0.f;
@@ -437,85 +446,92 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_bf16_kernel(BArgs a
         }
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) wl[tid + j * 256] = (unsigned short)bf16_bits(w2q[j]);
+      for (int j = 0; j < 2 * MT; ++j) wl[tid + j * 256] = (unsigned short)bf16_bits(w2q[j]);
       __syncthreads();
-      const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wl + lane * 8));
+      bf16x8 af[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) af[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wl + m * 512 + lane * 8));
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int p2 = ((wz * G::TY + wh + t / NH) * G::TW + (t % NH) * 16 + lj) + (lk & 1) * NPOS;
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xl + p2 * 4)), acc[t], 0, 0, 0);
+        const bf16x8 xf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xl + p2 * 4));
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], xf, acc[m][t], 0, 0, 0);
       }
     }
   }
 
   // ---- epilogue: D row = co (4*lk + r), D col = voxel lj (same layout as the fp32 16x16x4 MFMA) ---------------------------
-  const bool interior = od0 + G::TZ <= Do && oh0 + G::TY <= Ho && ow0 + G::TW <= Wo && n0 + 16 <= a.Cout;
+  const bool interior = od0 + G::TZ <= Do && oh0 + G::TY <= Ho && ow0 + G::TW <= Wo && n0 + 16 * MT <= a.Cout;
   const int vbase = ((od0 + wz) * Ho + oh0 + wh) * Wo + ow0 + lj;
-  if (a.accumulate) {                                          // all of the tile's destination values requested together, then added
-    float old[4][NT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = n0 + 4 * lk + r;
-      const float* __restrict__ yo = dpi_at(a.y, (size_t)(co < a.Cout ? co : 0) * Vo + vbase, a.yb);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
-        const bool ok = interior || (co < a.Cout && od < Do && oh < Ho && ow < Wo);
-        const size_t o = (t / NH) * Wo + (t % NH) * 16;
-        old[r][t] = ok ? (YB ? __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(yo)[o]) : yo[o]) : 0.f;     // bf16: raw, widened below
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t][r] += YB ? dpi_widen_raw(old[r][t]) : old[r][t];
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int co = n0 + 4 * lk + r;
-    const bool cok = co < a.Cout;
-    const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
-    float* __restrict__ yc = dpi_at(a.y, (size_t)(cok ? co : 0) * Vo + vbase, a.yb);
-    double s = 0.0, q = 0.0;
-    if (a.yb) {
-      // bf16 destination: two voxels per dword store where the rows are even-aligned (dpi_st_bf16_row); statistics describe what is stored
-      const bool pairs = !(Wo & 1) && !(Vo & 1) && !((uintptr_t)a.y & 3);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
-        const bool ok = interior || (cok && od < Do && oh < Ho && ow < Wo);
-        const float v = dpi_round_bf16(acc[t][r] + bv);
-        dpi_st_bf16_row(yc, (t / NH) * Wo + (t % NH) * 16, v, ok, pairs, lj);
-        if (ok) { s += v; q += (double)v * v; }
-      }
-    } else if (interior) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float v = acc[t][r] + bv;
-        yc[(t / NH) * Wo + (t % NH) * 16] = v;
-        if (a.partials) { s += v; q += (double)v * v; }
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
-        if (cok && od < Do && oh < Ho && ow < Wo) {
-          const float v = acc[t][r] + bv;
-          yc[(t / NH) * Wo + (t % NH) * 16] = v;
-          s += v;
-          q += (double)v * v;
+  for (int m = 0; m < MT; ++m) {
+    if (a.accumulate) {                                          // all of the tile's destination values requested together, then added
+      float old[4][NT];
+  #pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = n0 + 16 * m + 4 * lk + r;
+        const float* __restrict__ yo = dpi_at(a.y, (size_t)(co < a.Cout ? co : 0) * Vo + vbase, a.yb);
+  #pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
+          const bool ok = interior || (co < a.Cout && od < Do && oh < Ho && ow < Wo);
+          const size_t o = (t / NH) * Wo + (t % NH) * 16;
+          old[r][t] = ok ? (YB ? __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(yo)[o]) : yo[o]) : 0.f;     // bf16: raw, widened below
         }
       }
+  #pragma unroll
+      for (int r = 0; r < 4; ++r)
+  #pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t][r] += YB ? dpi_widen_raw(old[r][t]) : old[r][t];
     }
-    if (a.partials) {
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-      if (lj == 0) { red[wid][4 * lk + r][0] = s; red[wid][4 * lk + r][1] = q; }
+  #pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = n0 + 16 * m + 4 * lk + r;
+      const bool cok = co < a.Cout;
+      const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
+      float* __restrict__ yc = dpi_at(a.y, (size_t)(cok ? co : 0) * Vo + vbase, a.yb);
+      double s = 0.0, q = 0.0;
+      if (a.yb) {
+        // bf16 destination: two voxels per dword store where the rows are even-aligned (dpi_st_bf16_row); statistics describe what is stored
+        const bool pairs = !(Wo & 1) && !(Vo & 1) && !((uintptr_t)a.y & 3);
+  #pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
+          const bool ok = interior || (cok && od < Do && oh < Ho && ow < Wo);
+          const float v = dpi_round_bf16(acc[m][t][r] + bv);
+          dpi_st_bf16_row(yc, (t / NH) * Wo + (t % NH) * 16, v, ok, pairs, lj);
+          if (ok) { s += v; q += (double)v * v; }
+        }
+      } else if (interior) {
+  #pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float v = acc[m][t][r] + bv;
+          yc[(t / NH) * Wo + (t % NH) * 16] = v;
+          if (a.partials) { s += v; q += (double)v * v; }
+        }
+      } else {
+  #pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int od = od0 + wz, oh = oh0 + wh + t / NH, ow = ow0 + (t % NH) * 16 + lj;
+          if (cok && od < Do && oh < Ho && ow < Wo) {
+            const float v = acc[m][t][r] + bv;
+            yc[(t / NH) * Wo + (t % NH) * 16] = v;
+            s += v;
+            q += (double)v * v;
+          }
+        }
+      }
+      if (a.partials) {
+  #pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if (lj == 0) { red[wid][16 * m + 4 * lk + r][0] = s; red[wid][16 * m + 4 * lk + r][1] = q; }
+      }
     }
   }
   if (a.partials) {
     __syncthreads();
-    if (tid < 32) {
+    if (tid < 32 * MT) {
       const int c = tid >> 1, which = tid & 1;
       const double rsum = red[0][c][which] + red[1][c][which] + red[2][c][which] + red[3][c][which];
       if (n0 + c < a.Cout) a.partials[((size_t)tile_id * a.Cout + n0 + c) * 2 + which] = rsum;
@@ -528,9 +544,10 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void conv_bf16_kernel(BArgs a
 // conv_bf16_kernel launch, on its stream: a few microseconds over <= 1 MB, instead of the same gather by every tile of the main kernel.
 template <int KD, bool FLIP, int NS>
 __global__ __launch_bounds__(256) void conv_bf16_pack_kernel(const float* __restrict__ w, long w_out_stride, long w_in_stride, int Cin, int Cout,
-                                                             unsigned short* __restrict__ out) {
+                                                             unsigned short* __restrict__ out, int mt) {
   constexpr int TAPS = KD * 9, NTG = (TAPS + 3) / 4, WW = NTG * 512;
-  unsigned short* __restrict__ const o = out + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NS * WW;
+  // the mt 16-channel tiles of one workgroup of the main kernel lie side by side: [co block / mt][group][co block % mt]
+  unsigned short* __restrict__ const o = out + (((size_t)(blockIdx.y / mt) * gridDim.x + blockIdx.x) * mt + blockIdx.y % mt) * NS * WW;
   for (int q = threadIdx.x; q < WW; q += 256) {
     const int ci = blockIdx.x * 8 + (q & 7), co = blockIdx.y * 16 + ((q >> 3) & 15), tap = q >> 7;
     const bool ok = co < Cout && ci < Cin && tap < TAPS;
@@ -580,7 +597,7 @@ void* dpi_pack_slot(const void* w, int kd, int cin, int cout, int tag, size_t nb
   g_pack_slots.emplace(key, slot);
   return slot;
 }
-static size_t bf16_pack_bytes(int kd, int cin, int cout, int ns) { return (size_t)cdiv(cout, 16) * cdiv(cin, 8) * ns * ((kd * 9 + 3) / 4) * 512 * sizeof(unsigned short); }
+static size_t bf16_pack_bytes(int kd, int cin, int cout, int ns) { return (size_t)2 * cdiv(cout, 32) * cdiv(cin, 8) * ns * ((kd * 9 + 3) / 4) * 512 * sizeof(unsigned short); }
 
 // tile variant: the 4x4x32 tile (2-D: 1x16x32) while it still gives >= 512 workgroups, else row-band tiles of one depth slice.
 // (The 4x8x32 tile of the fp32 kernel needs 64 prefetch + 64 accumulator registers here and spills.)
@@ -642,12 +659,23 @@ int dpi_conv_bf16_stat_blocks(const dpi_conv_desc* d) {
   return bf16_tiles(d, nr, nh, &a, &b, &c);
 }
 
+template <int KD, bool FLIP, int NS, bool XB = false, bool YB = false, int MT = 1>
+static void launch_bf16_m(const BArgs& a, int nr, int nh, dim3 grid, hipStream_t st) {
+  if (nr == 4 && nh == 2) conv_bf16_kernel<KD, 4, 2, FLIP, NS, XB, YB, MT><<<grid, 256, 0, st>>>(a);
+  else if (nr == 4) conv_bf16_kernel<KD, 4, 1, FLIP, NS, XB, YB, MT><<<grid, 256, 0, st>>>(a);
+  else if (nh == 2) conv_bf16_kernel<KD, 2, 2, FLIP, NS, XB, YB, MT><<<grid, 256, 0, st>>>(a);
+  else conv_bf16_kernel<KD, 2, 1, FLIP, NS, XB, YB, MT><<<grid, 256, 0, st>>>(a);
+}
+// two output tiles per workgroup: only where the launch is short of workgroups anyway (the coarsest levels: 212->128 at 32x16x16 0.042 ->
+// 0.039 / 0.033 ms forward / backward, 71->106 0.022 -> 0.018); at full resolution the third and fourth workgroup per CU are worth more
+// than the shared staging (16->25 backward at 256x128x128: 0.245 -> 0.257 ms with 3 per CU, 0.286 with 2)
+static int bf16_mt(int kd, int cout, int ns, int nr, int ntiles) { return (kd == 3 && ns == 1 && cout > 16 && nr != 4 && ntiles * cdiv(cout, 16) <= 256) ? 2 : 1; }
 template <int KD, bool FLIP, int NS, bool XB = false, bool YB = false>
 static void launch_bf16_t(const BArgs& a, int nr, int nh, dim3 grid, hipStream_t st) {
-  if (nr == 4 && nh == 2) conv_bf16_kernel<KD, 4, 2, FLIP, NS, XB, YB><<<grid, 256, 0, st>>>(a);
-  else if (nr == 4) conv_bf16_kernel<KD, 4, 1, FLIP, NS, XB, YB><<<grid, 256, 0, st>>>(a);
-  else if (nh == 2) conv_bf16_kernel<KD, 2, 2, FLIP, NS, XB, YB><<<grid, 256, 0, st>>>(a);
-  else conv_bf16_kernel<KD, 2, 1, FLIP, NS, XB, YB><<<grid, 256, 0, st>>>(a);
+  if constexpr (KD == 3 && NS == 1) {
+    if (bf16_mt(KD, a.Cout, NS, nr, a.ntd * a.nth * a.ntw) == 2) { launch_bf16_m<KD, FLIP, NS, XB, YB, 2>(a, nr, nh, grid, st); return; }
+  }
+  launch_bf16_m<KD, FLIP, NS, XB, YB, 1>(a, nr, nh, grid, st);
 }
 template <int KD, bool FLIP, int NS>
 static void launch_bf16(const BArgs& a, int nr, int nh, dim3 grid, hipStream_t st) {
@@ -667,16 +695,18 @@ int dpi_conv_bf16_run(const dpi_conv_desc* d, const float* x, const float* chain
   int nr, nh;
   bf16_variant(d, cout, &nr, &nh);
   const int ns = d->precision == 2 ? 3 : 1;
-  unsigned short* const wpk = static_cast<unsigned short*>(dpi_pack_slot(w, d->kd, cin, cout, (flip ? 1 : 0) | (ns << 1), bf16_pack_bytes(d->kd, cin, cout, ns)));
+  int t0, t1, t2;
+  const int mt = bf16_mt(d->kd, cout, ns, nr, bf16_tiles(d, nr, nh, &t0, &t1, &t2));
+  unsigned short* const wpk = static_cast<unsigned short*>(dpi_pack_slot(w, d->kd, cin, cout, (flip ? 1 : 0) | (ns << 1) | (mt << 3), bf16_pack_bytes(d->kd, cin, cout, ns)));
   if (!wpk) return DPI_E_LAUNCH;
   {
-    const dim3 pg(cdiv(cin, 8), cdiv(cout, 16));
+    const dim3 pg(cdiv(cin, 8), cdiv(cout, 16 * mt) * mt);
     if (d->precision == 2) {
-      if (d->kd == 3) { if (flip) conv_bf16_pack_kernel<3, true, 3><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk); else conv_bf16_pack_kernel<3, false, 3><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk); }
-      else { if (flip) conv_bf16_pack_kernel<1, true, 3><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk); else conv_bf16_pack_kernel<1, false, 3><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk); }
+      if (d->kd == 3) { if (flip) conv_bf16_pack_kernel<3, true, 3><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk, mt); else conv_bf16_pack_kernel<3, false, 3><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk, mt); }
+      else { if (flip) conv_bf16_pack_kernel<1, true, 3><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk, mt); else conv_bf16_pack_kernel<1, false, 3><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk, mt); }
     } else {
-      if (d->kd == 3) { if (flip) conv_bf16_pack_kernel<3, true, 1><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk); else conv_bf16_pack_kernel<3, false, 1><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk); }
-      else { if (flip) conv_bf16_pack_kernel<1, true, 1><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk); else conv_bf16_pack_kernel<1, false, 1><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk); }
+      if (d->kd == 3) { if (flip) conv_bf16_pack_kernel<3, true, 1><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk, mt); else conv_bf16_pack_kernel<3, false, 1><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk, mt); }
+      else { if (flip) conv_bf16_pack_kernel<1, true, 1><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk, mt); else conv_bf16_pack_kernel<1, false, 1><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk, mt); }
     }
   }
   BArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, wpk, accumulate, g_bf16_debug,
@@ -684,7 +714,7 @@ int dpi_conv_bf16_run(const dpi_conv_desc* d, const float* x, const float* chain
   if (a.xb && (((uintptr_t)x & 7) || (sec && ((uintptr_t)sec->x2 & 7)))) { dpi_set_error("conv_bf16_mfma: a bf16 input tensor must be 8-byte aligned"); return DPI_E_ARG; }
   if (sec) { a.x2 = sec->x2; a.w2 = sec->w2; a.C2 = sec->C2; a.w2_co_stride = sec->w2_co_stride; a.w2_c_stride = sec->w2_c_stride; }
   const int ntiles = bf16_tiles(d, nr, nh, &a.ntd, &a.nth, &a.ntw);
-  dim3 grid(ntiles, cdiv(cout, 16));
+  dim3 grid(ntiles, cdiv(cout, 16 * mt));
   if (d->precision == 2) {
     if (d->kd == 3) { if (flip) launch_bf16<3, true, 3>(a, nr, nh, grid, st); else launch_bf16<3, false, 3>(a, nr, nh, grid, st); }
     else { if (flip) launch_bf16<1, true, 3>(a, nr, nh, grid, st); else launch_bf16<1, false, 3>(a, nr, nh, grid, st); }
