@@ -77,6 +77,9 @@ CONV_IO = [
     (13, 9, (7, 9, 11), 3, 1),        # odd row lengths: element-wise staging everywhere, dY rows not 8-byte aligned
     (7, 3, (9, 10, 12), 3, 1),        # VALU forward / backward-weight
     (13, 4, (32, 32, 40), 3, 1),      # few-output-channel backward-weight kernels (swapped MFMA orientation / smallco)
+    (16, 25, (16, 16, 34), 3, 1),     # W % 4 != 0: the bf16 kernel's 4-element staging pieces do not apply -> conv_mfma IOB in every mode
+    (40, 40, (4, 16, 32), 3, 1),      # row-band tiles, two 16-channel output tiles per workgroup (conv_bf16_kernel<..., MT = 2>), third tile ragged
+    (105, 64, (16, 16, 32), 3, 1),    # row-band tiles, one output tile per workgroup (plenty of workgroups), 13 channel groups + ragged last
 ]
 
 
@@ -125,6 +128,49 @@ def test_conv_kernels_with_bf16_tensors_vs_oracle(ops, cin, cout, shape, k, stri
     dw = torch.empty_like(wg)
     ops.raw_conv_bwd_weight(d, xg, None, dyg, dw)
     assert rel(dw, dwr) < 5e-6, rel(dw, dwr)
+
+
+@pytest.mark.parametrize("store", ["bf16", "fp32"])
+def test_packed_weights_follow_in_place_updates(ops, store):
+    """conv_bf16_kernel reads the weights from a per-layer packed copy that every launch rewrites (conv_bf16_pack_kernel): an optimiser
+    step that changes the weight tensor IN PLACE (same pointer, same slot) must show in the next launch, in both directions, eagerly
+    and when the launches are replayed from a captured graph."""
+    ops.set_precision("bf16mm")
+    adt = BF if store == "bf16" else torch.float32
+    x, w, b, dy, yr, dxr, _ = _conv_case(ops, 25, 16, (16, 32, 32), 3, 1, 77)
+    xg, wg, bg, dyg = x.to(DEV).to(adt), w.to(DEV).clone(), b.to(DEV), dy.to(DEV).to(adt)
+    d = ops.make_desc(xg, wg, 1, adt)
+    y, dx = torch.empty(yr.shape, dtype=adt, device=DEV), torch.empty(x.shape, dtype=adt, device=DEV)
+
+    def run():
+        ops.raw_conv_fwd(d, xg, None, wg, bg, y)
+        ops.raw_conv_bwd_data(d, dyg, wg, dx)
+
+    def check(wnow, what):
+        xr, wr = x.double(), wnow.double().cpu()
+        yref, dxref = O.conv_nd(xr, wr, b.double(), 1), torch.nn.grad.conv3d_input(x.shape, wr, dy.double(), padding=1)
+        if store == "bf16":
+            half_ulp_ok(y, yref, "y " + what)
+            half_ulp_ok(dx, dxref, "dx " + what)
+        else:                                        # fp32 tensors: the bf16 products are exact, fp32 accumulation
+            assert rel(y, yref) < 1e-5 and rel(dx, dxref) < 1e-5, (what, rel(y, yref), rel(dx, dxref))
+
+    run()
+    check(wg, "first launch")
+    wg.mul_(-0.5).add_(bf16_values(tuple(wg.shape), torch.Generator().manual_seed(3), 0.02).to(DEV))     # in place: same pointer
+    wg.copy_(wg.to(BF).float())                                                                           # keep the products exact
+    run()
+    check(wg, "after an in-place update")
+    g = torch.cuda.CUDAGraph()
+    s_ = torch.cuda.Stream()
+    with torch.cuda.stream(s_):
+        with torch.cuda.graph(g, stream=s_):
+            run()
+    wg.copy_((wg * 1.5 + 0.01).to(BF).float())
+    y.zero_(); dx.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    check(wg, "graph replay after another update")
 
 
 @pytest.mark.parametrize("xbf,ybf", [(True, False), (False, True)])
