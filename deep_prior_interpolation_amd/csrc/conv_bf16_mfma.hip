@@ -43,6 +43,7 @@ struct BArgs {
   int Cin, Cout;
   int D, H, W;
   int ntd, nth, ntw;
+  int ny;          // output-channel tiles of the launch (workgroups per spatial tile)
   long w_out_stride, w_in_stride;
   const unsigned short* __restrict__ wpk;      // the weights as bf16 A fragments (conv_bf16_pack_kernel), written before this launch
   int accumulate;
@@ -94,9 +95,17 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 }
 __device__ __forceinline__ unsigned bf16_bits(float f) { return pack_bf16(f, 0.f) & 0xffffu; }
 
-__device__ __forceinline__ int xcd_tile_b(int bid, int ntiles) {        // contiguous tile range per XCD (see conv_mfma.hip)
-  const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, i = bid >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+// Workgroup -> (spatial tile, output-channel tile).  Workgroups go to the 8 XCDs round-robin by their linear id; XCD x walks a contiguous
+// range of tiles (neighbours share halo lines in ITS L2, as in conv_mfma.hip) and runs the ny channel tiles of a spatial tile BACK TO
+// BACK: they read the same input tile (and the same second input); with the channel tile as the slow grid dimension they ran a whole
+// launch apart and every pass over the input came from HBM again.  The grid is 8 * ceil(ntiles / 8) * ny workgroups; the few past an
+// XCD's range leave at once (false).
+__device__ __forceinline__ bool xcd_tile_b(int bid, int ntiles, int ny, int& tile, int& ytile) {
+  const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, j = bid >> 3;
+  const int i = j / ny;
+  ytile = j - i * ny;
+  tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  return i < q + (xcd < r ? 1 : 0);
 }
 
 // exact three-term split of an fp32 value into bf16 bit patterns
@@ -134,13 +143,13 @@ __global__ __launch_bounds__(256, NS != 1 ? 2 : MT == 2 ? 3 : 4) void conv_bf16_
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lk = lane >> 4, lj = lane & 15;
-  const int n0 = blockIdx.y * 16 * MT;
+  int tile_id, ytile;
+  if (!xcd_tile_b(blockIdx.x, a.ntd * a.nth * a.ntw, a.ny, tile_id, ytile)) return;
+  const int n0 = ytile * 16 * MT;
   const size_t V = (size_t)a.D * a.H * a.W;
-  const int ntiles = a.ntd * a.nth * a.ntw;
   const int Do = a.D, Ho = a.H, Wo = a.W;                      // stride 1, 'same' padding
   const size_t Vo = V;
 
-  const int tile_id = xcd_tile_b(blockIdx.x, ntiles);
   int od0, oh0, ow0;
   {
     int bt = tile_id;
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(256, NS != 1 ? 2 : MT == 2 ? 3 : 4) void conv_bf16_
   // order instead trades them for bank conflicts of the 2-byte staging writes (0.27 / 0.30 ms) (profiles/README.md, round 4).
   constexpr int WV = MT * NS * WW / 8, WPE = (WV + 255) / 256; // 16-byte pieces of a group's fragments; per thread
   u32x4 wq[WPE];                                               // next channel group's pieces of this thread
-  const u32x4* __restrict__ const wsrc = reinterpret_cast<const u32x4*>(a.wpk) + (size_t)blockIdx.y * ((a.Cin + 7) >> 3) * WV;
+  const u32x4* __restrict__ const wsrc = reinterpret_cast<const u32x4*>(a.wpk) + (size_t)ytile * ((a.Cin + 7) >> 3) * WV;
   auto load_w = [&](int c0) {
 #pragma unroll
     for (int j = 0; j < WPE; ++j) {
@@ -709,12 +718,13 @@ int dpi_conv_bf16_run(const dpi_conv_desc* d, const float* x, const float* chain
       else { if (flip) conv_bf16_pack_kernel<1, true, 1><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk, mt); else conv_bf16_pack_kernel<1, false, 1><<<pg, 256, 0, st>>>(w, w_out, w_in, cin, cout, wpk, mt); }
     }
   }
-  BArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, w_out, w_in, wpk, accumulate, g_bf16_debug,
+  BArgs a{x, chain, w, bias, y, partials, cin, cout, d->D, d->H, d->W, 0, 0, 0, 0, w_out, w_in, wpk, accumulate, g_bf16_debug,
           dpi_io_in(d, flip), dpi_io_out(d, flip), nullptr, nullptr, 0, 0, 0};
   if (a.xb && (((uintptr_t)x & 7) || (sec && ((uintptr_t)sec->x2 & 7)))) { dpi_set_error("conv_bf16_mfma: a bf16 input tensor must be 8-byte aligned"); return DPI_E_ARG; }
   if (sec) { a.x2 = sec->x2; a.w2 = sec->w2; a.C2 = sec->C2; a.w2_co_stride = sec->w2_co_stride; a.w2_c_stride = sec->w2_c_stride; }
   const int ntiles = bf16_tiles(d, nr, nh, &a.ntd, &a.nth, &a.ntw);
-  dim3 grid(ntiles, cdiv(cout, 16 * mt));
+  a.ny = cdiv(cout, 16 * mt);
+  dim3 grid(8 * cdiv(ntiles, 8) * a.ny);
   if (d->precision == 2) {
     if (d->kd == 3) { if (flip) launch_bf16<3, true, 3>(a, nr, nh, grid, st); else launch_bf16<3, false, 3>(a, nr, nh, grid, st); }
     else { if (flip) launch_bf16<1, true, 3>(a, nr, nh, grid, st); else launch_bf16<1, false, 3>(a, nr, nh, grid, st); }
