@@ -273,9 +273,10 @@ def run_c2(a, rank, world, device):
     del vol, mask
 
     mode = a.mode
-    if mode == "auto":                      # big patches are GPU-bound either way; small ones are launch-bound without a graph
-        mode = "eager" if V >= (1 << 20) else "graph"
-    overlap = V >= (1 << 20) and WGRAD_OVERLAP     # --mode graph on a big patch: the side stream is captured into the graph too
+    overlap = T.wants_weight_grad_overlap() and WGRAD_OVERLAP     # >= 2^20 voxels, fp32 storage (Interpolator.wants_weight_grad_overlap)
+    if mode == "auto":                      # as Interpolator.optimize: eager where the side streams pay, else one hipGraph replay per iteration
+        mode = "eager" if overlap else "graph"
+    # (--mode graph on a big fp32 patch: the side stream is captured into the graph too)
     ops.set_weight_grad_overlap(overlap, in_graph=(mode == "graph" and overlap))
 
     def eager_step():

@@ -165,6 +165,13 @@ class Interpolator:
         # bf16 STORAGE of the activations (BASELINE configs[4]) where every node of the net is a fused 3-D node that takes it
         ops.set_storage("bf16" if (prec == "bf16" and self.storage_bf16_ok()) else "fp32")
 
+    def wants_weight_grad_overlap(self):
+        """Weight gradients on side streams next to the backward-data chain: patches of >= 2^20 voxels in the fp32 modes (+1-3 % there).
+        With bf16 activations the kernels of the main chain are latency- rather than MFMA-bound and lose more to the side streams' workgroups
+        than the overlap gives: 20.2 ms with, 18.9 ms without at 256x128x128, 18.3 ms replayed from a graph (profiles/README.md, round 4)."""
+        big = int(np.prod(self.img.shape[:-1])) >= (1 << 20)
+        return big and not (getattr(self.args, "precision", "fp32") == "bf16" and self.storage_bf16_ok())
+
     def storage_bf16_ok(self):
         """Whether this net runs with bf16 activations: the 3-D MultiRes-UNet whose blocks all execute as the fused nodes
         (LeakyReLU, no dropout) — Block3dFn / SkipJoinFn / ConvBnActFn allocate the tensors and every kernel under them takes the
@@ -255,13 +262,13 @@ class Interpolator:
         "auto" picks "graph" unless per-iteration host work was requested (net_inputs, --save_every) or the patch has
         >= 2^20 voxels."""
         a = self.args
+        big = self.wants_weight_grad_overlap()
         if mode == "auto":
-            # big patches are GPU-bound either way and gain from overlapping the weight gradients (eager only);
+            # big fp32 patches are GPU-bound either way and gain from overlapping the weight gradients (eager only);
             # small ones are launch-bound without a graph
             mode = "eager" if (net_inputs is not None or a.save_every is not None or a.epochs < 3 or self.has_regularizer()
-                               or a.data_forgetting_factor != 0 or int(np.prod(self.img.shape[:-1])) >= (1 << 20)) else "graph"
+                               or a.data_forgetting_factor != 0 or big) else "graph"
         self.optimizer = FusedAdam(self.net.parameters(), lr=a.lr)
-        big = int(np.prod(self.img.shape[:-1])) >= (1 << 20)
         ops.set_weight_grad_overlap(big, in_graph=(mode == "graph" and big))
         start = time()
         if mode == "graph":
@@ -297,7 +304,7 @@ class Interpolator:
             # prepared directly (optimize_concurrently, bench.py): the weight-gradient side streams follow THIS patch's size, not
             # whatever an earlier optimize() in the process left behind; optimize() / bench.py set it before they
             # call graph_prepare with an optimiser of their own
-            big = int(np.prod(self.img.shape[:-1])) >= (1 << 20)
+            big = self.wants_weight_grad_overlap()
             ops.set_weight_grad_overlap(big, in_graph=big)
         opt = self.optimizer
         self._g_state = torch.zeros(8, dtype=torch.float64, device=dev)
