@@ -403,7 +403,9 @@ def run_c2(a, rank, world, device):
         iso = d_iso["flop"] / (d_iso["ms"] * 1e-3) / 1e12
         best_l = max((l for l in layers if l[0] == "conv_fwd" and l[1][5] == 3), key=lambda l: l[3] / l[2], default=None)
         whole = {"achieved_tflops": round(iter_flop / (ms * 1e-3) / 1e12, 3),
-                 "algorithmic_bytes_per_iteration": bmin, "binding_roofline_ms": round(iter_flop / (FP32_PEAK_TFLOPS * 1e12) * 1e3, 3)}
+                 "algorithmic_bytes_per_iteration": bmin, "binding_roofline_ms": round(bmin / (HBM_PEAK_GBS * 1e9) * 1e3 if a.precision == "bf16"
+                                              else iter_flop / (FP32_PEAK_TFLOPS * 1e12) * 1e3, 3),
+                 "binding_roofline": "HBM (bf16 B_min / 8 TB/s)" if a.precision == "bf16" else "fp32 FMA (algorithmic FLOPs / 157.3 TFLOP/s)"}
         frac_fp32 = round(iter_flop / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
         frac_hbm = round(bmin / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         traffic = traffic_src = moa = None
@@ -427,8 +429,8 @@ def run_c2(a, rank, world, device):
         # not the kernel — they are reported beside it.  For families that never leave the main stream the two agree.
         fam_name = FAMILY_NAMES.get(dom_key, str(dom_key))
         if a.precision in ("bf16", "bf16mm") and dom_key[1:] == (3, 1):       # the bf16 arithmetic modes serve this family with their own kernels
-            fam_name = {"conv_fwd": "forward 3x3x3 stride 1 (conv_bf16_kernel<3,..> on the big tiles, conv_mfma_kernel below)",
-                        "conv_bwd_data": "backward-data 3x3x3 stride 1 (conv_bf16_kernel<3,..,FLIP> with the 1x1x1 siblings fused in, conv_mfma_kernel on the coarse levels)",
+            fam_name = {"conv_fwd": "forward 3x3x3 stride 1 (conv_bf16_kernel<3,..>: 4x4x32 tiles, row-band tiles on the coarse levels)",
+                        "conv_bwd_data": "backward-data 3x3x3 stride 1 (conv_bf16_kernel<3,..,FLIP> with the 1x1x1 siblings fused in; row-band tiles on the coarse levels)",
                         "conv_bwd_weight": "backward-weight 3x3x3 stride 1 (conv_bf16_bwd_weight_kernel)"}[dom_key[0]]
         roof = {"bound": "mfma", "kernel": fam_name + " @%dx%dx%d: the kernel family with the largest share of the iteration"
                          % tuple(a.patch),
