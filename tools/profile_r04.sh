@@ -4,7 +4,7 @@
 #   -> gpurun_out/<prefix>_kernel_stats.txt, _by_grid.txt, _layers.txt, _overlap_on.txt, _hbm_iteration_{FETCH,WRITE}_SIZE.txt,
 #      _family_{FETCH,WRITE}_SIZE.txt, <prefix>_traffic.json
 # Every rocprofv3 invocation has `python3 <script>` directly after `--`; counter passes are separate runs whose only trace domain
-# is the kernel trace the counters attach to.  The profiled command is bench.py's default workload with 3 timed steps; bench.py
+# is the kernel trace the counters attach to.  The profiled command is bench.py's default workload (eager loop) with 3 timed steps; bench.py
 # itself runs 3 untimed iterations before them (first touch, the per-family timing pass, one warm-up): 6 iterations per file.
 set -u
 pre=$1; shift
@@ -14,7 +14,9 @@ out=$repo/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 ITERS=6
-BENCH="$repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-modes --no-c3-extra ${BENCH_EXTRA:-}"
+# --mode eager: a fixed number of iterations per file whatever the precision (the bf16 line replays a graph by default and then adds an
+# eager tail for the per-launch events: 10 iterations); the kernels are the same in both loop modes
+BENCH="$repo/bench.py --mode eager --steps 3 --warmup 1 --no-cpu-baseline --no-other-modes --no-c3-extra ${BENCH_EXTRA:-}"
 
 trace() {
   local name=$1
