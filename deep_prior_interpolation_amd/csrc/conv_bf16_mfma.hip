@@ -24,6 +24,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 void dpi_conv_out_dims(const dpi_conv_desc* d, int* Do, int* Ho, int* Wo);
 
@@ -578,7 +579,8 @@ __global__ __launch_bounds__(256) void conv_bf16_pack_kernel(const float* __rest
 // runs on a stream of its own) would need its region allocated during the capture, and two graphs captured on one stream would share one.
 // A layer first seen during a capture takes its slot from a chunk that already exists (hipMalloc is not capturable): run one eager
 // iteration first, as for every captured workload here.
-static constexpr size_t kPackChunk = 64u << 20, kPackMaxSlot = 16u << 20;
+static constexpr size_t kPackChunk = 64u << 20, kPackMaxSlot = 16u << 20, kPackMaxTotal = (size_t)4 << 30;
+static std::vector<void*> g_pack_chunks;
 static std::mutex g_pack_mutex;
 static std::map<std::tuple<const void*, int, int, int, int>, void*> g_pack_slots;
 static char* g_pack_chunk = nullptr;
@@ -593,11 +595,17 @@ void* dpi_pack_slot(const void* w, int kd, int cin, int cout, int tag, size_t nb
   if (bytes > kPackChunk) { dpi_set_error("packed-weight scratch: %zu bytes in one slot", bytes); return nullptr; }
   if (g_pack_used + bytes > kPackChunk) {
     void* p = nullptr;
+    if ((g_pack_chunks.size() + 1) * kPackChunk > kPackMaxTotal) {
+      dpi_set_error("packed-weight scratch: %zu MB held for %zu (weight tensor, shape) pairs; call dpi_pack_release()", g_pack_chunks.size() * (kPackChunk >> 20),
+                    g_pack_slots.size());
+      return nullptr;
+    }
     if (hipMalloc(&p, kPackChunk) != hipSuccess) {
       (void)hipGetLastError();
       dpi_set_error("cannot allocate packed-weight scratch (a layer's first launch inside a graph capture? run one eager iteration first)");
       return nullptr;
     }
+    g_pack_chunks.push_back(p);
     g_pack_chunk = static_cast<char*>(p);
     g_pack_used = 0;
   }
@@ -605,6 +613,20 @@ void* dpi_pack_slot(const void* w, int kd, int cin, int cout, int tag, size_t nb
   g_pack_used += bytes;
   g_pack_slots.emplace(key, slot);
   return slot;
+}
+extern "C" size_t dpi_pack_scratch_bytes(void) {
+  std::lock_guard<std::mutex> lock(g_pack_mutex);
+  return g_pack_chunks.size() * kPackChunk;
+}
+extern "C" int dpi_pack_release(void) {
+  std::lock_guard<std::mutex> lock(g_pack_mutex);
+  if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); dpi_set_error("dpi_pack_release: hipDeviceSynchronize failed"); return DPI_E_LAUNCH; }
+  for (void* p : g_pack_chunks) (void)hipFree(p);
+  g_pack_chunks.clear();
+  g_pack_slots.clear();
+  g_pack_chunk = nullptr;
+  g_pack_used = kPackChunk;
+  return DPI_OK;
 }
 static size_t bf16_pack_bytes(int kd, int cin, int cout, int ns) { return (size_t)2 * cdiv(cout, 32) * cdiv(cin, 8) * ns * ((kd * 9 + 3) / 4) * 512 * sizeof(unsigned short); }
 

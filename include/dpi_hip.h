@@ -44,7 +44,7 @@ extern "C" {
 
 const char* dpi_last_error(void);
 /* ABI version: 300 = round 3 (dpi_conv_desc carries its own size as first field), 301 adds dpi_conv_fwd_ws / dpi_conv_bwd_data_ws /
- * dpi_conv_bwd_data_dual, 400 = round 4: dpi_conv_desc grows the `io` field (bf16 storage of activations) and the elementwise entry
+ * dpi_conv_bwd_data_dual, 401 = dpi_pack_scratch_bytes / dpi_pack_release, 400 = round 4: dpi_conv_desc grows the `io` field (bf16 storage of activations) and the elementwise entry
  * points get `_io` twins that take the storage types of their tensors.  A binding checks `>=` the version it was written against and
  * dpi_conv_desc_size() == its own struct size. */
 int dpi_version(void);
@@ -392,6 +392,21 @@ size_t dpi_max_ws_floats(size_t n);
 int dpi_scaled_max(const float* x, size_t n, float scale, float* ws, float* out, void* stream);
 int dpi_threshold(const float* x, size_t n, const float* thresh, float* y, void* stream);
 int dpi_pocs_project(const float* x, const float* wdata, const float* wmask, size_t n, float* y, void* stream);
+
+/* ---------------------------------------------------------------- packed-weight scratch (ABI 401) --------------------------------
+ * No reference counterpart (torch's convolutions own their workspaces the same way).  In the bf16 arithmetic modes the 3x3(x3) stride-1
+ * stencil kernel reads its weights from a bf16 copy in MFMA-fragment order that a small kernel writes in front of EVERY launch, on the
+ * launch's stream, into the layer's slot of a library-owned scratch: one slot per (weight pointer, shape, direction), carved from 64 MB
+ * hipMalloc chunks at the layer's first launch and kept.  Consequences for a caller:
+ *   - the weight tensor itself is never cached: whatever wrote it before the launch is what the launch uses;
+ *   - a layer's FIRST launch must not happen inside a stream capture unless a chunk with room already exists (hipMalloc is not
+ *     capturable): run one eager iteration before capturing, as for any captured workload;
+ *   - the scratch grows with the number of distinct (weight pointer, shape) pairs seen, up to 4 GB; beyond that launches fail with
+ *     DPI_E_LAUNCH until dpi_pack_release() is called.
+ * dpi_pack_scratch_bytes(): bytes currently held.  dpi_pack_release(): hipDeviceSynchronize(), then frees every chunk and forgets every
+ * slot; the caller guarantees that no graph captured before the call is launched after it (its kernels hold slot addresses). */
+size_t dpi_pack_scratch_bytes(void);
+int dpi_pack_release(void);
 
 #ifdef __cplusplus
 }

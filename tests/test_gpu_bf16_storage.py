@@ -173,6 +173,24 @@ def test_packed_weights_follow_in_place_updates(ops, store):
     check(wg, "graph replay after another update")
 
 
+def test_pack_scratch_release_and_regrow(ops):
+    """ABI 401: dpi_pack_release() hands the packed-weight scratch back; the next launch allocates a fresh slot and is still right."""
+    ops.set_precision("bf16mm")
+    L = ops._lib.load()
+    x, w, b, dy, yr, dxr, _ = _conv_case(ops, 16, 16, (8, 16, 32), 3, 1, 5)
+    xg, wg, bg = x.to(DEV).to(BF), w.to(DEV), b.to(DEV)
+    d = ops.make_desc(xg, wg, 1, BF)
+    y = torch.empty(yr.shape, dtype=BF, device=DEV)
+    ops.raw_conv_fwd(d, xg, None, wg, bg, y)
+    held = L.dpi_pack_scratch_bytes()
+    assert held >= (64 << 20) and held % (64 << 20) == 0
+    assert L.dpi_pack_release() == 0 and L.dpi_pack_scratch_bytes() == 0
+    y.zero_()
+    ops.raw_conv_fwd(d, xg, None, wg, bg, y)
+    assert L.dpi_pack_scratch_bytes() == (64 << 20)
+    half_ulp_ok(y, yr, "y after dpi_pack_release")
+
+
 @pytest.mark.parametrize("xbf,ybf", [(True, False), (False, True)])
 @pytest.mark.parametrize("cin,cout,shape,k,stride", [(25, 1, (32, 32, 64), 3, 1), (8, 13, (64, 64, 64), 3, 1), (35, 53, (8, 16, 16), 3, 1),
                                                      (25, 25, (16, 32, 32), 3, 2), (64, 25, (16, 16, 32), 1, 1), (7, 3, (9, 10, 12), 3, 1)])
