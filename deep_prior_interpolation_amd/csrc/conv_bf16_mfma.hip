@@ -1,22 +1,23 @@
 // bf16-MFMA stencil convolution (k = 3, stride 1; forward and backward-data) for gfx950 — the mixed-precision mode of
 // BASELINE configs[4] ("bf16 activations + fp32 master weights"): operands are rounded to bf16 (round-to-nearest-even) while
-// they are staged into LDS, products are exact in fp32 and accumulate in fp32 (v_mfma_f32_16x16x32_bf16), tensors in HBM and
-// the master weights stay fp32, BatchNorm statistics / Adam stay fp32.  16x the matrix rate of the fp32 MFMA path
-// (conv_mfma.hip), so the kernel is bound by its LDS operand reads and, beyond that, by HBM.
+// they are staged into LDS, products are exact in fp32 and accumulate in fp32 (v_mfma_f32_16x16x32_bf16); the activation tensors
+// are fp32 or bf16 in HBM (dpi_conv_desc.io, template parameters XB / YB), the master weights, BatchNorm statistics and Adam stay
+// fp32.  16x the matrix rate of the fp32 MFMA path (conv_mfma.hip): the MFMA phase is bound by its LDS operand reads, the kernel
+// as a whole by the latency of the next channel group's tile at 4 workgroups per CU.
 //
 // Implicit GEMM per output tile:   D[co 16][vox 16] += A[co 16][K 32] * B[K 32][vox 16]
 //     K block = 8 input channels x 4 taps (tap = 4 g + lane>>4, g = 0 .. ceil(TAPS / 4) - 1): a small channel count still fills K,
 //     and one staged group of 8 channels serves all 27 taps.
 //     B = halo tile in LDS as [position][8 channels] bf16 (16 B per position): lane (vox = l & 15, tap slot = l >> 4) reads ONE
 //         ds_read_b128 at position(vox) + offset(tap) — 16 consecutive positions per 16-lane group, conflict-free.
-//     A = weights of the 8-channel group, converted to bf16 by the workgroup once per group and shared through LDS as ready-made
-//         fragments [g][lane][8] (the torch layout [Cout][Cin][27] would cost every lane 8 strided loads per fragment).
+//     A = weights of the 8-channel group as ready-made fragments [g][lane][8] in LDS, copied 16 bytes per thread from the layer's
+//         PACKED bf16 copy (conv_bf16_pack_kernel, one small launch in front of every launch of this kernel; the torch layout
+//         [Cout][Cin][27] gathered by every tile cost 64 cache-line lookups per load instruction and bound the kernel).
 // NS = 3 (precision = 2, "split" mode): every fp32 operand is split EXACTLY into three bf16 terms x = h + m + l (8 + 8 + 8
 // significant bits; h = rne(x), m = rne(x - h), l = rne(x - h - m), each difference exact in fp32) and six of the nine partial
 // products — hh, hm, mh, mm, hl, lh, i.e. all those >= 2^-16 of the full product — are accumulated in fp32.  The three dropped
 // ones are <= 2^-24 relative each, the size of one fp32 rounding, so the result carries fp32-class accuracy (verified against
-// the fp64 oracle at the fp32 path's own tolerance) at 16 / 6 = 2.7 x the fp32 matrix rate; since the kernel is bound by its
-// staging loads, not by the matrix pipe, the extra MFMAs are close to free.
+// the fp64 oracle at the fp32 path's own tolerance) at 16 / 6 = 2.7 x the fp32 matrix rate.
 // Workgroup = 4 waves = output tile 4x4x32 (or the small 1x8x16/32 variants for coarse levels), as in conv_mfma.hip; D layout,
 // epilogue (bias, BatchNorm {sum, sum^2} partials, gradient fan-in) are those of the fp32 kernel.
 #include "common.h"
@@ -62,9 +63,9 @@ struct BArgs {
 };
 
 // WIDE (bf16 input tensors): the halo tile starts 4 columns left of the output tile and is 8 columns wider than it, so that every row is
-// a whole number of ALIGNED 4-element pieces (8 bytes of a bf16 tensor): one load instruction per piece instead of one per element.  The
-// kernel is bound by the NUMBER of staging loads, not their bytes (tools/bench_conv.py --bf16-debug: 25->16 forward 0.273 ms, 0.142 ms
-// without the global loads): 16 instead of 40 load instructions per thread and 8-channel group.
+// a whole number of ALIGNED 4-element pieces (8 bytes of a bf16 tensor): one load instruction per piece instead of one per element —
+// 16 instead of 40 load instructions per thread and 8-channel group, 32 instead of 48 prefetch registers.  (Neutral on time by itself:
+// what the phase-skipping runs had attributed to the x loads were the weight gathers, DESIGN §3 / profiles/README.md round 4.)
 template <int KD, int NR, int NH, bool WIDE = false>
 struct GeoB {
   static constexpr bool SLICES = (KD == 3 && NR >= 4);          // waves split depth; otherwise they split rows
