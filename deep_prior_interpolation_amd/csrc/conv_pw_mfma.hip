@@ -354,6 +354,93 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_weight_mfma_kernel(PwBwArgs a
   }
 }
 
+// bf16-MFMA variant for bf16 tensors in the bf16 arithmetic mode (dpi_conv_desc.precision = 1, io: x and dy bf16, V a multiple of 8):
+//     dW[co][ci] = sum_v dY[co][v] * T(X)[ci][v]      as      D[co 16][ci 16] += A[co 16][K 32 voxels] * B[K 32 voxels][ci 16]
+// K runs over VOXELS, and 8 consecutive voxels of a channel row are 16 contiguous bytes of a bf16 tensor — exactly one lane's share of a
+// v_mfma_f32_16x16x32_bf16 operand (lane = (row lj, octet lk)).  Both operands therefore go from global memory straight into MFMA
+// registers: no LDS, no transposition, no conversion when X has no chain (with one: widen, apply, round to bf16 — the operand rounding of
+// the mode, as in conv_bf16_bwd_weight_kernel).  The fp32-MFMA kernel above spends 16 cycles per 4 voxels of a 16 x 16 tile, this one 16
+// per 32: 67->25 at 256x128x128 is matrix-bound there (0.35 ms for 0.77 GB) and HBM-bound here.
+typedef __bf16 pw_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int pw_u32x4 __attribute__((ext_vector_type(4)));
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void conv_pw_bwd_weight_bf16_kernel(PwBwArgs a) {
+  constexpr int U = 2;                                   // 32-voxel steps in flight per wave (4: no faster, 208-248 registers)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int ci0 = blockIdx.y * 16 * NT, co0 = blockIdx.z * 16 * MT;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  Chain ch[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) ch[n] = load_chain(a.chain, min(ci0 + n * 16 + lj, a.Cin - 1));
+  const size_t vbeg = (size_t)blockIdx.x * a.vox_per_chunk;
+  const size_t vend = vbeg + a.vox_per_chunk < a.V ? vbeg + a.vox_per_chunk : a.V;
+  // rows past Cout / Cin re-read the last real channel (their products land in rows / columns that are never written)
+  const unsigned short* __restrict__ dyr[MT];
+  const unsigned short* __restrict__ xr[NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) dyr[m] = reinterpret_cast<const unsigned short*>(a.dy) + (size_t)min(co0 + m * 16 + lj, a.Cout - 1) * a.V;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) xr[n] = reinterpret_cast<const unsigned short*>(a.x) + (size_t)min(ci0 + n * 16 + lj, a.Cin - 1) * a.V;
+  const int mt_valid = min(MT, (a.Cout - co0 + 15) / 16), nt_valid = min(NT, (a.Cin - ci0 + 15) / 16);
+  for (size_t g0 = vbeg + (size_t)wid * (32 * U); g0 < vend; g0 += 4 * 32 * U) {
+    pw_u32x4 ga[U][MT], xb[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t v = g0 + 32 * u + 8 * lk;             // this lane's octet: whole or absent (V, the chunk length and g0 are multiples of 8)
+      const bool in = v < vend;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        if (m < mt_valid) ga[u][m] = in ? *reinterpret_cast<const pw_u32x4*>(dyr[m] + v) : (pw_u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        if (n < nt_valid) xb[u][n] = in ? *reinterpret_cast<const pw_u32x4*>(xr[n] + v) : (pw_u32x4){0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (a.chain) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          if (n < nt_valid) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const unsigned w2 = xb[u][n][k];
+              const float lo = apply_chain(ch[n], __builtin_bit_cast(float, w2 << 16)), hi = apply_chain(ch[n], __builtin_bit_cast(float, w2 & 0xffff0000u));
+              xb[u][n][k] = dpi_pack_bf16(lo, hi);        // (an absent octet meets dY = 0)
+            }
+          }
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        if (m < mt_valid) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            if (n < nt_valid)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pw_bf16x8, ga[u][m]), __builtin_bit_cast(pw_bf16x8, xb[u][n]), acc[m][n], 0, 0, 0);
+        }
+    }
+  }
+  // cross-wave reduction; D row = co (4*lk + r), col = ci lj
+  __shared__ float red[4][MT * NT * 4 * 64];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wid][((m * NT + n) * 4 + r) * 64 + lane] = acc[m][n][r];
+  __syncthreads();
+  for (int e = tid; e < MT * NT * 4 * 64; e += 256) {
+    const int l = e & 63, r = (e >> 6) & 3, n = (e >> 8) % NT, m = (e >> 8) / NT;
+    const int co = co0 + m * 16 + 4 * (l >> 4) + r, ci = ci0 + n * 16 + (l & 15);
+    if (co < a.Cout && ci < a.Cin)
+      a.ws[((size_t)blockIdx.x * a.Cout + co) * a.Cin + ci] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+  }
+}
+
 __global__ void reduce_chunks_pw_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n, int nchunks) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = gid >> 3;
@@ -450,7 +537,19 @@ int dpi_conv_pw_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, cons
       else conv_pw_bwd_weight_mfma_kernel<2, 4, XB, DYB><<<grid, 256, 0, st>>>(a);
     }
   };
-  if (a.xb && a.dyb) launch(std::true_type{}, std::true_type{});
+  // both tensors bf16 in the bf16 arithmetic mode: operands straight from memory into the bf16 MFMA (16-byte octets: V % 8, aligned bases)
+  if (a.xb && a.dyb && d->precision == 1 && (a.V & 7) == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0) {
+    if (p.mt == 1) {
+      if (p.nt == 1) conv_pw_bwd_weight_bf16_kernel<1, 1><<<grid, 256, 0, st>>>(a);
+      else if (p.nt == 2) conv_pw_bwd_weight_bf16_kernel<1, 2><<<grid, 256, 0, st>>>(a);
+      else conv_pw_bwd_weight_bf16_kernel<1, 4><<<grid, 256, 0, st>>>(a);
+    } else {
+      if (p.nt == 1) conv_pw_bwd_weight_bf16_kernel<2, 1><<<grid, 256, 0, st>>>(a);
+      else if (p.nt == 2) conv_pw_bwd_weight_bf16_kernel<2, 2><<<grid, 256, 0, st>>>(a);
+      else conv_pw_bwd_weight_bf16_kernel<2, 4><<<grid, 256, 0, st>>>(a);
+    }
+  }
+  else if (a.xb && a.dyb) launch(std::true_type{}, std::true_type{});
   else if (a.xb) launch(std::true_type{}, std::false_type{});
   else if (a.dyb) launch(std::false_type{}, std::true_type{});
   else launch(std::false_type{}, std::false_type{});

@@ -173,6 +173,37 @@ def test_packed_weights_follow_in_place_updates(ops, store):
     check(wg, "graph replay after another update")
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(64, 25, (16, 16, 32)), (67, 25, (8, 16, 24)), (137, 51, (4, 8, 16)), (7, 3, (2, 4, 8))])
+def test_pointwise_backward_weight_on_the_bf16_mfma(ops, cin, cout, shape):
+    """conv_pw_bwd_weight_bf16_kernel (1x1x1, x and dy bf16, bf16 arithmetic, V % 8 == 0): operands go from memory straight into the bf16
+    MFMA.  Without a chain the products are exact (the fp32 kernels' tolerance); with the producer's chain T(x) is rounded to bf16 as
+    an operand (2^-9 relative per element, uncorrelated), and the result must agree with the oracle fed that rounded T(x) tightly."""
+    ops.set_precision("bf16mm")
+    gen = torch.Generator().manual_seed(cin + cout)
+    x = bf16_values((1, cin) + shape, gen)
+    w = bf16_values((cout, cin, 1, 1, 1), gen, 0.1)
+    dy = bf16_values((1, cout) + shape, gen)
+    xg, dyg, wg = x.to(DEV).to(BF), dy.to(DEV).to(BF), w.to(DEV)
+    d = ops.make_desc(xg, wg, 1, BF)
+    assert d.io == 15 and d.precision == 1
+    dw = torch.empty_like(wg)
+    ops.raw_conv_bwd_weight(d, xg, None, dyg, dw)
+    ref = torch.einsum("ov,iv->oi", dy.double().reshape(cout, -1), x.double().reshape(cin, -1)).reshape(wg.shape)
+    assert rel(dw, ref) < 5e-6, rel(dw, ref)
+    chain = torch.stack([torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen) * 0.3, torch.full((cin,), 0.2),
+                         torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen) * 0.1], 1).contiguous()
+    ps, pb, sl, qs, qb = (chain[:, i].view(1, cin, 1, 1, 1) for i in range(5))
+    v = ps * x + pb                                       # fp32, the kernel's own arithmetic (apply_chain: no contraction)
+    tx = qs * torch.where(v > 0, v, v * sl) + qb
+    ops.raw_conv_bwd_weight(d, xg, chain.to(DEV), dyg, dw)
+    ref_r = torch.einsum("ov,iv->oi", dy.double().reshape(cout, -1), tx.to(BF).double().reshape(cin, -1)).reshape(wg.shape)
+    ref_x = torch.einsum("ov,iv->oi", dy.double().reshape(cout, -1), tx.double().reshape(cin, -1)).reshape(wg.shape)
+    assert rel(dw, ref_x) < 4e-3, rel(dw, ref_x)
+    # the MFMA kernel rounds T(x) (a few values may round the other way: fp32 association of the chain); the VALU kernel that serves the
+    # few-channel layer keeps T(x) in fp32
+    assert rel(dw, ref_r) < 2e-4 or rel(dw, ref_x) < 5e-6, (rel(dw, ref_r), rel(dw, ref_x))
+
+
 def test_pack_scratch_release_and_regrow(ops):
     """ABI 401: dpi_pack_release() hands the packed-weight scratch back; the next launch allocates a fresh slot and is still right."""
     ops.set_precision("bf16mm")
