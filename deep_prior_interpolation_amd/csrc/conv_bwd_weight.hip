@@ -25,6 +25,10 @@ int dpi_conv_bwd_weight_smallco_run(const dpi_conv_desc* d, const float* x, cons
 bool dpi_conv_bf16_bww_usable(const dpi_conv_desc* d);
 size_t dpi_conv_bf16_bww_ws_floats(const dpi_conv_desc* d);
 int dpi_conv_bf16_bww_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* dy, float* dw, float* ws, hipStream_t st);
+// conv_bf16_bww_s2.hip: 3x3x3 stride 2, x and dy bf16, bf16 arithmetic, no chain
+bool dpi_conv_bf16_bww_s2_usable(const dpi_conv_desc* d);
+size_t dpi_conv_bf16_bww_s2_ws_floats(const dpi_conv_desc* d);
+int dpi_conv_bf16_bww_s2_run(const dpi_conv_desc* d, const float* x, const float* dy, float* dw, float* ws, hipStream_t st);
 static bool bw_use_smallco(const dpi_conv_desc* d) {
   return d->k == 3 && d->kd == 3 && d->stride == 1 && d->Cout <= 5 && (size_t)d->D * d->H * d->W >= 32768 &&
          (size_t)d->D * d->H * d->W < ((size_t)1 << 26);   // one 32-bit buffer offset spans the (<= 5) dY channels
@@ -293,6 +297,11 @@ BwPlan plan(const dpi_conv_desc* d) {
 
 extern "C" size_t dpi_conv_bwd_weight_ws_floats(const dpi_conv_desc* d) {
   if (dpi_check_conv_desc(d) != DPI_OK) return 0;
+  if (dpi_conv_bf16_bww_s2_usable(d)) {       // whether it runs depends on the chain and the alignment given at launch: size for both
+    dpi_conv_desc f = *d;
+    f.precision = 0;
+    return std::max(dpi_conv_bf16_bww_s2_ws_floats(d), dpi_conv_bwd_weight_ws_floats(&f));
+  }
   if (dpi_conv_bf16_bww_usable(d)) {          // the fp32 kernels stay the fallback for unaligned views: size for both
     dpi_conv_desc f = *d;
     f.precision = 0;
@@ -316,6 +325,13 @@ extern "C" int dpi_conv_bwd_weight(const dpi_conv_desc* d, const float* x, const
   hipStream_t st = (hipStream_t)stream;
   // staging loads of 4 values: 16 bytes from an fp32 tensor, 8 from a bf16 one
   const uintptr_t misal = ((uintptr_t)x & ((d->io & DPI_IO_X_BF16) ? 7 : 15)) | ((uintptr_t)dy & ((d->io & DPI_IO_DY_BF16) ? 7 : 15));
+  if (dpi_conv_bf16_bww_s2_usable(d) && x_chain == nullptr && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0) {
+    if (ws_floats < dpi_conv_bf16_bww_s2_ws_floats(d)) {
+      dpi_set_error("conv_bwd_weight: workspace %zu < %zu floats", ws_floats, dpi_conv_bf16_bww_s2_ws_floats(d));
+      return DPI_E_WORKSPACE;
+    }
+    return dpi_conv_bf16_bww_s2_run(d, x, dy, dw, ws, st);
+  }
   if (dpi_conv_bf16_bww_usable(d) && misal == 0) {
     if (ws_floats < dpi_conv_bf16_bww_ws_floats(d)) {
       dpi_set_error("conv_bwd_weight: workspace %zu < %zu floats", ws_floats, dpi_conv_bf16_bww_ws_floats(d));
