@@ -68,7 +68,8 @@ CONV_IO = [
     (25, 1, (32, 32, 64), 3, 1),      # the output layer's shape (y fp32 in the net; here bf16 as well)
     (35, 53, (8, 16, 16), 3, 1),      # coarse level: small-tile conv_mfma, input-channel split off / on below
     (212, 71, (4, 8, 8), 3, 1),       # input-channel split (workspace) + splitk_reduce_kernel storing bf16
-    (25, 25, (16, 32, 32), 3, 2),     # stride 2: conv_mfma<..,S=2>, conv_bwd_data_s2_mfma, conv_bwd_weight_mfma<..,S=2>
+    (25, 25, (16, 32, 32), 3, 2),     # stride 2: conv_mfma<..,S=2>, conv_bwd_data_s2_mfma; backward-weight: conv_bf16_bww_s2_kernel<2> in bf16 mode (W % 16 == 0)
+    (40, 13, (7, 9, 48), 3, 2),       # ... odd depth / height (rows past the end of x), one output tile, three 16-channel input tiles, ragged last octet chunk
     (51, 51, (9, 11, 13), 3, 2),      # stride 2, odd sizes
     (3, 5, (6, 6, 6), 3, 2),          # VALU stride-2 kernels (few channels)
     (64, 25, (16, 16, 32), 1, 1),     # 1x1x1 MFMA forward / backward-data / backward-weight
