@@ -118,7 +118,7 @@ BwS2Plan bww_s2_plan(const dpi_conv_desc* d) {
   p.noct = p.Do * p.Ho * (p.Wo / 8);
   const long other = (long)cdiv(d->Cin, 16) * cdiv(d->Cout, 32);
   const size_t per = (size_t)d->Cout * d->Cin * 27;
-  long want = cdiv(1536, (int)other);                                    // ~6 workgroups of 3 waves per CU
+  long want = 1280 / other;                                              // ONE round of workgroups: 5 of 3 waves are resident per CU at 126 registers
   const long steps = cdiv(p.noct, 4);
   if (want > steps) want = steps;
   const long max_mem = (long)(((size_t)16 << 20) / per);                 // <= 64 MB of partial sums

@@ -453,6 +453,10 @@ __global__ void reduce_chunks_pw_kernel(const float* __restrict__ ws, float* __r
 }
 
 struct PwBwPlan { int nchunks; size_t vox_per_chunk; int mt, nt; };
+// whether conv_pw_bwd_weight_bf16_kernel serves the layer (x and dy bf16, bf16 arithmetic, 16-byte octets); alignment is checked at launch
+static bool pw_bw_bf16(const dpi_conv_desc* d) {
+  return d->precision == 1 && (d->io & DPI_IO_X_BF16) && (d->io & DPI_IO_DY_BF16) && (((size_t)d->D * d->H * d->W) & 7) == 0;
+}
 PwBwPlan pw_bw_plan(const dpi_conv_desc* d) {
   PwBwPlan p{};
   const size_t V = (size_t)d->D * d->H * d->W;
@@ -538,7 +542,7 @@ int dpi_conv_pw_bwd_weight_mfma_run(const dpi_conv_desc* d, const float* x, cons
     }
   };
   // both tensors bf16 in the bf16 arithmetic mode: operands straight from memory into the bf16 MFMA (16-byte octets: V % 8, aligned bases)
-  if (a.xb && a.dyb && d->precision == 1 && (a.V & 7) == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0) {
+  if (pw_bw_bf16(d) && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0) {
     if (p.mt == 1) {
       if (p.nt == 1) conv_pw_bwd_weight_bf16_kernel<1, 1><<<grid, 256, 0, st>>>(a);
       else if (p.nt == 2) conv_pw_bwd_weight_bf16_kernel<1, 2><<<grid, 256, 0, st>>>(a);
