@@ -141,13 +141,15 @@ def mid_name(shape):
     return ("snr_bench_head_%s.npz" if tuple(shape) == (256, 128, 128) else "snr_mid_%s.npz") % tag
 
 
-def merge_mid(shape):
-    """-> tests/golden/snr_mid_<shape>.npz from the per-seed parts (complete or not: `iterations` says how far each seed got)."""
+def merge_mid(shape, min_iterations=0):
+    """-> tests/golden/snr_mid_<shape>.npz from the per-seed parts (complete or not: `iterations` says how far each seed got;
+    `min_iterations` leaves out seeds that are still short of it — the ones running when the merge is made)."""
     import hashlib
     tag = "x".join(str(n) for n in shape)
     files = sorted(glob.glob(os.path.join(mid_part_dir(shape), "seed*.npz")))
     files = [f for f in files if ".tmp." not in f]
     parts = [dict(np.load(f)) for f in files]
+    parts = [p for p in parts if len(p["loss"]) >= min_iterations]
     n = min(len(p["loss"]) for p in parts)
     vol, mask = stand_in(tuple(shape), dense=True)
     out = {"shape": np.array(shape), "argv": np.array(" ".join(ARGV)), "torch": np.array(torch.__version__),
@@ -187,9 +189,10 @@ if __name__ == "__main__":
     ap.add_argument("--merge", action="store_true")
     ap.add_argument("--plateau", type=int, nargs=3, default=None, metavar=("NT", "NX", "NY"))
     ap.add_argument("--mid", type=int, nargs=3, default=None, metavar=("NT", "NX", "NY"))
+    ap.add_argument("--min-iterations", type=int, default=0, help="--mid --merge: leave out seeds with fewer recorded iterations")
     a = ap.parse_args()
     if a.mid and a.merge:
-        merge_mid(a.mid)
+        merge_mid(a.mid, a.min_iterations)
         sys.exit(0)
     ref_shim.install()
     if a.mid:
