@@ -572,6 +572,189 @@ __global__ __launch_bounds__(256) void conv_bf16_pack_kernel(const float* __rest
   }
 }
 
+
+// ---- stride 2 (forward, bf16 tensors): the four down-sampling layers (mulresunet.py:185-199, nn.Conv3d(.., 3, stride=2, padding=1)) ----------
+// Same implicit GEMM, tile and fragment layouts as above with two changes.  (1) A workgroup owns a 2 x 4 x 16 OUTPUT tile (wave = (slice,
+// row pair), two 16-voxel blocks per wave) and stages the 5 x 9 x 40 input tile that starts 4 columns left of column 2 ow0 (whole aligned
+// 4-element pieces, as GeoB WIDE).  (2) The tile is stored with EVEN and ODD input columns in separate planes —
+// position(dz, hy, col) = ((dz * 9 + hy) * 2 + (col & 1)) * 20 + (col >> 1) — so that the 16 lanes of a B-fragment read, which want input
+// columns 2 ow + kw - 1 for 16 consecutive ow, read 16 consecutive positions (conflict-free) instead of every second one.
+// MT output-channel tiles per workgroup (the tile is small: 8 accumulator registers per channel tile).
+struct S2Args {
+  const float* __restrict__ x;
+  const float* __restrict__ chain;
+  const float* __restrict__ bias;
+  float* __restrict__ y;
+  double* __restrict__ partials;
+  const unsigned short* __restrict__ wpk;
+  int Cin, Cout;
+  int D, H, W, Do, Ho, Wo;
+  int ntd, nth, ntw, ny;
+};
+
+template <int MT>
+__global__ __launch_bounds__(256, 4) void conv_bf16_s2_kernel(S2Args a) {
+  constexpr int TAPS = 27, NTG = 7, WW = NTG * 512;
+  constexpr int TZ = 2, TY = 4, TW = 16, ID = 5, IH = 9, IW = 40, HP = IW / 2;            // HP: positions per parity plane of a row
+  constexpr int TILE = ID * IH * IW, NQ = ID * IH * (IW / 4), EQ = (NQ + 255) / 256;
+  constexpr int WV = MT * WW / 8, WPE = (WV + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned xl[TILE * 4];
+  __shared__ __attribute__((aligned(16))) unsigned short wl[MT * WW];
+  __shared__ double red[4][16 * MT][2];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  int tile_id, ytile;
+  if (!xcd_tile_b(blockIdx.x, a.ntd * a.nth * a.ntw, a.ny, tile_id, ytile)) return;
+  const int n0 = ytile * 16 * MT;
+  const size_t V = (size_t)a.D * a.H * a.W, Vo = (size_t)a.Do * a.Ho * a.Wo;
+  int od0, oh0, ow0;
+  {
+    int bt = tile_id;
+    const int tw_i = bt % a.ntw; bt /= a.ntw;
+    const int th_i = bt % a.nth; bt /= a.nth;
+    od0 = bt * TZ; oh0 = th_i * TY; ow0 = tw_i * TW;
+  }
+  const int wz = wid >> 1, wh = (wid & 1) * 2;                 // this wave: output slice wz, rows wh, wh + 1
+  // this thread's 4-element pieces of the input tile: global element offset (or -1) and first position of the piece's row
+  int qoff[EQ], qrow[EQ];
+#pragma unroll
+  for (int e = 0; e < EQ; ++e) {
+    const int qi = tid + e * 256;
+    const int q = qi % (IW / 4), row = qi / (IW / 4);
+    const int hy = row % IH, dz = row / IH;
+    const int gd = 2 * od0 - 1 + dz, gh = 2 * oh0 - 1 + hy, gw = 2 * ow0 - 4 + 4 * q;
+    const bool ok = qi < NQ && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+    qoff[e] = ok ? (gd * a.H + gh) * a.W + gw : -1;
+    qrow[e] = (dz * IH + hy) * IW + 2 * q;                     // columns 4q .. 4q+3 -> plane (j & 1), index 2q + (j >> 1)
+  }
+  int toff[NTG];
+#pragma unroll
+  for (int g = 0; g < NTG; ++g) {
+    const int t = min(4 * g + lk, TAPS - 1);
+    const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+    // input column 2 ow + kw - 1 = tile column 2 ow_l + kw + 3: parity of kw + 3, index ow_l + (kw + 3) / 2
+    toff[g] = (kd * IH + kh) * IW + ((kw + 3) & 1) * HP + ((kw + 3) >> 1);
+  }
+  const int pbase = (2 * wz * IH + 2 * wh) * IW + lj;         // output (wz, wh, lj) at tap (0, 0, 0): tile row (2 wz, 2 wh)
+
+  unsigned sq[8][EQ][2];
+  auto load_x = [&](int c0) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int ci = min(c0 + c, a.Cin - 1);
+      const __amdgpu_buffer_rsrc_t r = dpi_buffer_t(dpi_at(a.x, (size_t)ci * V, true), V, true);
+#pragma unroll
+      for (int e = 0; e < EQ; ++e) {
+        const dpi_u32x2v u = __builtin_bit_cast(dpi_u32x2v, __builtin_amdgcn_raw_buffer_load_b64(r, qoff[e] >= 0 ? qoff[e] * 2 : -8, 0, 0));
+        sq[c][e][0] = u.x; sq[c][e][1] = u.y;
+      }
+    }
+  };
+  u32x4 wq[WPE];
+  const u32x4* __restrict__ const wsrc = reinterpret_cast<const u32x4*>(a.wpk) + (size_t)ytile * ((a.Cin + 7) >> 3) * WV;
+  auto load_w = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < WPE; ++j) {
+      const int i = tid + j * 256;
+      wq[j] = wsrc[(c0 >> 3) * WV + ((j + 1) * 256 <= WV || i < WV ? i : 0)];
+    }
+  };
+  load_x(0); load_w(0);
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = acc[m][0]; }
+
+  for (int c0 = 0; c0 < a.Cin; c0 += 8) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EQ; ++e) {
+      const int qi = tid + e * 256;
+      if ((e + 1) * 256 <= NQ || qi < NQ) {
+        unsigned o[4][4];
+        if (a.chain == nullptr) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[j][k] = __builtin_amdgcn_perm(sq[2 * k + 1][e][j >> 1], sq[2 * k][e][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
+        } else {
+          const bool in = qoff[e] >= 0;                       // zero padding stays zero
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const Chain ch0 = load_chain(a.chain, min(c0 + 2 * k, a.Cin - 1)), ch1 = load_chain(a.chain, min(c0 + 2 * k + 1, a.Cin - 1));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const unsigned u0 = sq[2 * k][e][j >> 1], u1 = sq[2 * k + 1][e][j >> 1];
+              const float x0 = __builtin_bit_cast(float, (j & 1) ? (u0 & 0xffff0000u) : (u0 << 16));
+              const float x1 = __builtin_bit_cast(float, (j & 1) ? (u1 & 0xffff0000u) : (u1 << 16));
+              o[j][k] = pack_bf16(in ? apply_chain(ch0, x0) : x0, in ? apply_chain(ch1, x1) : x1);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<u32x4*>(xl + (qrow[e] + (j & 1) * HP + (j >> 1)) * 4) = (u32x4){o[j][0], o[j][1], o[j][2], o[j][3]};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WPE; ++j) {
+      const int i = tid + j * 256;
+      if ((j + 1) * 256 <= WV || i < WV) *reinterpret_cast<u32x4*>(wl + i * 8) = wq[j];
+    }
+    __syncthreads();
+    if (c0 + 8 < a.Cin) { load_x(c0 + 8); load_w(c0 + 8); }
+#pragma unroll
+    for (int g = 0; g < NTG; ++g) {
+      int pg = pbase + toff[g];
+      asm volatile("" : "+v"(pg));
+      bf16x8 af[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) af[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wl + m * WW + (g * 64 + lane) * 8));
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 xf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xl + (pg + t * 2 * IW) * 4));
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], xf, acc[m][t], 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: D row = co (4 lk + r), D col = output voxel lj of rows wh, wh + 1 of slice wz
+  const int od = od0 + wz;
+  const bool pairs = !(a.Wo & 1) && !(Vo & 1) && !((uintptr_t)a.y & 3);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = n0 + 16 * m + 4 * lk + r;
+      const bool cok = co < a.Cout;
+      const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
+      double s = 0.0, q = 0.0;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int oh = oh0 + wh + t, ow = ow0 + lj;
+        const bool ok = cok && od < a.Do && oh < a.Ho && ow < a.Wo;
+        const float v = dpi_round_bf16(acc[m][t][r] + bv);
+        float* __restrict__ yc = dpi_at(a.y, (size_t)(cok ? co : 0) * Vo + ((size_t)min(od, a.Do - 1) * a.Ho + min(oh, a.Ho - 1)) * a.Wo + ow0, true);
+        dpi_st_bf16_row(yc, lj, v, ok, pairs, lj);
+        if (ok) { s += v; q += (double)v * v; }
+      }
+      if (a.partials) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if (lj == 0) { red[wid][16 * m + 4 * lk + r][0] = s; red[wid][16 * m + 4 * lk + r][1] = q; }
+      }
+    }
+  }
+  if (a.partials) {
+    __syncthreads();
+    if (tid < 32 * MT) {
+      const int c = tid >> 1, which = tid & 1;
+      const double rsum = red[0][c][which] + red[1][c][which] + red[2][c][which] + red[3][c][which];
+      if (n0 + c < a.Cout) a.partials[((size_t)tile_id * a.Cout + n0 + c) * 2 + which] = rsum;
+    }
+  }
+}
+
 }  // namespace
 
 // Packed-weight scratch: one slot per (weight tensor, direction, shape, kernel family), carved from 64 MB chunks and kept for the life of
@@ -756,4 +939,35 @@ int dpi_conv_bf16_run(const dpi_conv_desc* d, const float* x, const float* chain
     else { if (flip) launch_bf16<1, true, 1>(a, nr, nh, grid, st); else launch_bf16<1, false, 1>(a, nr, nh, grid, st); }
   }
   return dpi_check_launch("conv_bf16_mfma");
+}
+
+// ---- stride-2 forward on the bf16 MFMA (conv_bf16_s2_kernel): bf16 x and y, bf16 arithmetic, rows of whole 4-element pieces ------------------
+bool dpi_conv_bf16_s2_usable(const dpi_conv_desc* d) {
+  return d->precision == 1 && d->k == 3 && d->kd == 3 && d->stride == 2 && (d->io & DPI_IO_X_BF16) && (d->io & DPI_IO_Y_BF16) && (d->W & 3) == 0
+         && (size_t)d->D * d->H * d->W < ((size_t)1 << 30) && bf16_pack_bytes(3, d->Cin, d->Cout, 1) * 2 <= kPackMaxSlot;
+}
+static int bf16_s2_tiles(const dpi_conv_desc* d, int* ntd, int* nth, int* ntw) {
+  int Do, Ho, Wo;
+  dpi_conv_out_dims(d, &Do, &Ho, &Wo);
+  *ntd = cdiv(Do, 2); *nth = cdiv(Ho, 4); *ntw = cdiv(Wo, 16);
+  return *ntd * *nth * *ntw;
+}
+int dpi_conv_bf16_s2_stat_blocks(const dpi_conv_desc* d) { int a, b, c; return bf16_s2_tiles(d, &a, &b, &c); }
+int dpi_conv_bf16_s2_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y, double* partials,
+                         hipStream_t st) {
+  if ((uintptr_t)x & 7) { dpi_set_error("conv_bf16_s2: a bf16 input tensor must be 8-byte aligned"); return DPI_E_ARG; }
+  const int mt = d->Cout > 32 ? 4 : (d->Cout > 16 ? 2 : 1);
+  const int cout_pad = cdiv(d->Cout, 16 * mt) * mt;            // 16-channel tiles written by the pack kernel
+  unsigned short* const wpk = static_cast<unsigned short*>(dpi_pack_slot(w, 3, d->Cin, d->Cout, 32 | (mt << 6),
+                                                                         (size_t)cout_pad * cdiv(d->Cin, 8) * 7 * 512 * sizeof(unsigned short)));
+  if (!wpk) return DPI_E_LAUNCH;
+  conv_bf16_pack_kernel<3, false, 1><<<dim3(cdiv(d->Cin, 8), cout_pad), 256, 0, st>>>(w, (long)d->Cin * 27, 27, d->Cin, d->Cout, wpk, mt);
+  S2Args a{x, chain, bias, y, partials, wpk, d->Cin, d->Cout, d->D, d->H, d->W, 0, 0, 0, 0, 0, 0, cdiv(d->Cout, 16 * mt)};
+  dpi_conv_out_dims(d, &a.Do, &a.Ho, &a.Wo);
+  const int ntiles = bf16_s2_tiles(d, &a.ntd, &a.nth, &a.ntw);
+  const dim3 grid(8 * cdiv(ntiles, 8) * a.ny);
+  if (mt == 4) conv_bf16_s2_kernel<4><<<grid, 256, 0, st>>>(a);
+  else if (mt == 2) conv_bf16_s2_kernel<2><<<grid, 256, 0, st>>>(a);
+  else conv_bf16_s2_kernel<1><<<grid, 256, 0, st>>>(a);
+  return dpi_check_launch("conv_bf16_s2");
 }

@@ -474,6 +474,11 @@ void dpi_mfma_variant(const dpi_conv_desc* d, int cout, int* nr, int* nh);
 int dpi_mfma_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth, int* ntw);
 bool dpi_mfma_half_tile(const dpi_conv_desc* d, bool flip);
 bool dpi_conv_bf16_usable(const dpi_conv_desc* d, bool flip);
+// conv_bf16_mfma.hip: 3x3x3 stride-2 forward, bf16 x and y, bf16 arithmetic
+bool dpi_conv_bf16_s2_usable(const dpi_conv_desc* d);
+int dpi_conv_bf16_s2_stat_blocks(const dpi_conv_desc* d);
+int dpi_conv_bf16_s2_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y, double* partials,
+                         hipStream_t st);
 int dpi_conv_bf16_stat_blocks(const dpi_conv_desc* d);
 int dpi_conv_bf16_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y,
                       double* partials, bool flip, int accumulate, hipStream_t st, const MfmaSecond* sec = nullptr);
@@ -492,6 +497,7 @@ extern "C" int dpi_conv_fwd_stat_blocks(const dpi_conv_desc* d) {
   if (check_desc(d) != DPI_OK) return 0;
   int Do, Ho, Wo;
   dpi_conv_out_dims(d, &Do, &Ho, &Wo);
+  if (dpi_conv_bf16_s2_usable(d)) return dpi_conv_bf16_s2_stat_blocks(d);
   if (dpi_conv_bf16_usable(d, false)) return dpi_conv_bf16_stat_blocks(d);
   if (dpi_conv_q4_usable(d, false)) { int a, b, c; return dpi_conv_q4_tiles(d, &a, &b, &c); }
   if (d->k == 1 && d->Cout >= g_mfma_min_cout) {
@@ -527,6 +533,7 @@ static int conv_run(const dpi_conv_desc* d, const float* x, const float* chain, 
   const int taps = d->kd * d->k * d->k;
   const int cin = flip ? d->Cout : d->Cin, cout = flip ? d->Cin : d->Cout;
   const long w_out = flip ? taps : (long)d->Cin * taps, w_in = flip ? (long)d->Cin * taps : taps;
+  if (!flip && !accumulate && dpi_conv_bf16_s2_usable(d)) return dpi_conv_bf16_s2_run(d, x, chain, w, bias, y, partials, st);
   if (dpi_conv_bf16_usable(d, flip)) return dpi_conv_bf16_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
   if (dpi_conv_q4_usable(d, flip)) return dpi_conv_q4_run(d, x, chain, w, bias, y, partials, flip, accumulate, st);
   const int xb = dpi_io_in(d, flip), yb = dpi_io_out(d, flip);
