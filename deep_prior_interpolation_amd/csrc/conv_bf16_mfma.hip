@@ -755,6 +755,174 @@ __global__ __launch_bounds__(256, 4) void conv_bf16_s2_kernel(S2Args a) {
   }
 }
 
+
+// ---- stride 2, backward-data (bf16 tensors): dx[ci][i] = sum_co sum_k W[co][ci][k] dY[co][o] over the taps with i = 2 o + k - 1 per axis -----
+// An even fine index has ONE such tap per axis (k = 1, o = i / 2), an odd one two (k = 0, o = (i + 1) / 2; k = 2, o = (i - 1) / 2): the eight
+// parity classes (pd, ph, pw) of the output have 1 / 2 / 2 / 4 / 2 / 4 / 4 / 8 of the 27 taps.  GEMM per class:
+//     D[ci 16][16 fine voxels of one parity along w] += A[ci 16][K 32 = 4 taps x 8 co] * B[K][voxels]
+// with B from the small coarse dY tile in LDS ([position][8 co], 2 x 3 x 20 positions for a 2 x 4 x 32 fine tile: voxel j of a class reads
+// coarse column j or j + 1 — consecutive positions) and A from a class-wise packing of the weights (conv_bf16_s2_bwd_pack_kernel: nine K
+// blocks per (16 ci, 8 co): classes 0 .. 6 one each, class 7 two; unused tap slots zero).  9 MFMAs per 8 dY channels and fine tile instead of
+// the 7 x 8 of a zero-inserted stride-1 launch.  Wave = (depth parity, row pair); the two w-parities of a row sit in the same lane, so the
+// epilogue stores (and, for a gradient fan-in, first reads) one packed dword per lane.
+struct S2BArgs {
+  const float* __restrict__ dy;
+  float* __restrict__ dx;
+  const unsigned short* __restrict__ wpk;
+  int Cin, Cout;               // of the layer: dx has Cin channels, dy Cout
+  int D, H, W, Do, Ho, Wo;
+  int ntd, nth, ntw, ny;
+  int accumulate;
+};
+
+// tap and coarse offset of K-slot q of parity class (pd, ph, pw): a parity-1 axis takes one bit of q (w first, then h, then d):
+// bit 0 -> k = 0, coarse offset +1;  bit 1 -> k = 2, offset 0;  a parity-0 axis: k = 1, offset 0.  false: the class has fewer slots.
+__host__ __device__ __forceinline__ bool s2_slot(int pd, int ph, int pw, int q, int& kd, int& kh, int& kw, int& od, int& oh, int& ow) {
+  const int n = pd + ph + pw;
+  const bool valid = q < (1 << n);
+  const int vw = pw ? (q & 1) : 0; q = pw ? q >> 1 : q;
+  const int vh = ph ? (q & 1) : 0; q = ph ? q >> 1 : q;
+  const int vd = pd ? (q & 1) : 0;
+  kw = pw ? (vw ? 2 : 0) : 1; ow = pw ? (vw ? 0 : 1) : 0;
+  kh = ph ? (vh ? 2 : 0) : 1; oh = ph ? (vh ? 0 : 1) : 0;
+  kd = pd ? (vd ? 2 : 0) : 1; od = pd ? (vd ? 0 : 1) : 0;
+  return valid;
+}
+
+__global__ __launch_bounds__(256) void conv_bf16_s2_bwd_pack_kernel(const float* __restrict__ w, int Cin, int Cout, unsigned short* __restrict__ out, int mt) {
+  // block (co group, ci tile) -> [9 K blocks][lane = (slot lk, ci lj)][8 co]; tiles of one workgroup side by side: [tile / mt][group][tile % mt]
+  unsigned short* __restrict__ const o = out + (((size_t)(blockIdx.y / mt) * gridDim.x + blockIdx.x) * mt + blockIdx.y % mt) * (9 * 512);
+  for (int e = threadIdx.x; e < 9 * 512; e += 256) {
+    const int blk = e >> 9, lane = (e >> 3) & 63, j = e & 7;
+    const int c8 = blk < 8 ? blk : 7, s_ = blk == 8 ? 1 : 0;
+    int kd, kh, kw, od, oh, ow;
+    const bool valid = s2_slot(c8 >> 2, (c8 >> 1) & 1, c8 & 1, 4 * s_ + (lane >> 4), kd, kh, kw, od, oh, ow);
+    const int co = blockIdx.x * 8 + j, ci = blockIdx.y * 16 + (lane & 15);
+    const float v = (valid && co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * 27 + (kd * 3 + kh) * 3 + kw] : 0.f;
+    o[e] = (unsigned short)bf16_bits(v);
+  }
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, 4) void conv_bf16_s2_bwd_kernel(S2BArgs a) {
+  constexpr int CH = 3, CW = 20, TILE = 2 * CH * CW, NQ = 2 * CH * (CW / 4);
+  constexpr int WB = 9 * 512, WV = MT * WB / 8, WPE = (WV + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned xl[TILE * 4];
+  __shared__ __attribute__((aligned(16))) unsigned short wl[MT * WB];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  int tile_id, ytile;
+  if (!xcd_tile_b(blockIdx.x, a.ntd * a.nth * a.ntw, a.ny, tile_id, ytile)) return;
+  const int m0 = ytile * 16 * MT;
+  const size_t V = (size_t)a.D * a.H * a.W, Vo = (size_t)a.Do * a.Ho * a.Wo;
+  int cd0, ch0, cw0;                                           // coarse origin of the tile; the fine origin is twice that
+  {
+    int bt = tile_id;
+    const int tw_i = bt % a.ntw; bt /= a.ntw;
+    const int th_i = bt % a.nth; bt /= a.nth;
+    cd0 = bt; ch0 = 2 * th_i; cw0 = 16 * tw_i;
+  }
+  const int pd = wid & 1, bh = wid >> 1;                       // this wave: fine slice 2 cd0 + pd, fine rows 2 ch0 + 2 bh + {0, 1}
+  // staging: threads 0 .. 29 own one 4-element piece of the coarse tile each (8 channels of it per group)
+  int qoff, qpos;
+  {
+    const int q = tid % (CW / 4), row = tid / (CW / 4);
+    const int cy = row % CH, cz = row / CH;
+    const int gd = cd0 + cz, gh = ch0 + cy, gw = cw0 + 4 * q;
+    const bool ok = tid < NQ && gd < a.Do && gh < a.Ho && gw < a.Wo;
+    qoff = ok ? (gd * a.Ho + gh) * a.Wo + gw : -1;
+    qpos = (cz * CH + cy) * CW + 4 * q;
+  }
+  // this wave's K blocks: classes (pd, ph, pw) for (ph, pw) = 00, 01, 10, 11 and, for pd = 1, the second block of class 111
+  const int nblk = pd ? 5 : 4;
+  int poff[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int ph = i < 4 ? (i >> 1) : 1, pw = i < 4 ? (i & 1) : 1;
+    int kd, kh, kw, od, oh, ow;
+    s2_slot(pd, ph, pw, (i == 4 ? 4 : 0) + lk, kd, kh, kw, od, oh, ow);
+    poff[i] = (od * CH + bh + oh) * CW + ow + lj;
+  }
+  unsigned sq[8][2];
+  auto load_x = [&](int c0) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int co = min(c0 + c, a.Cout - 1);                  // channels past Cout: their weights are zero
+      const __amdgpu_buffer_rsrc_t r = dpi_buffer_t(dpi_at(a.dy, (size_t)co * Vo, true), Vo, true);
+      const dpi_u32x2v u = __builtin_bit_cast(dpi_u32x2v, __builtin_amdgcn_raw_buffer_load_b64(r, qoff >= 0 ? qoff * 2 : -8, 0, 0));
+      sq[c][0] = u.x; sq[c][1] = u.y;
+    }
+  };
+  u32x4 wq[WPE];
+  const u32x4* __restrict__ const wsrc = reinterpret_cast<const u32x4*>(a.wpk) + (size_t)ytile * ((a.Cout + 7) >> 3) * WV;
+  auto load_w = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < WPE; ++j) {
+      const int i = tid + j * 256;
+      wq[j] = wsrc[(c0 >> 3) * WV + ((j + 1) * 256 <= WV || i < WV ? i : 0)];
+    }
+  };
+  load_x(0); load_w(0);
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[m][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int c0 = 0; c0 < a.Cout; c0 += 8) {
+    __syncthreads();
+    if (tid < NQ) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = __builtin_amdgcn_perm(sq[2 * k + 1][j >> 1], sq[2 * k][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
+        *reinterpret_cast<u32x4*>(xl + (qpos + j) * 4) = (u32x4){o[0], o[1], o[2], o[3]};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WPE; ++j) {
+      const int i = tid + j * 256;
+      if ((j + 1) * 256 <= WV || i < WV) *reinterpret_cast<u32x4*>(wl + i * 8) = wq[j];
+    }
+    __syncthreads();
+    if (c0 + 8 < a.Cout) { load_x(c0 + 8); load_w(c0 + 8); }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      if (i < nblk) {                                          // wave-uniform
+        const int blk = pd ? (i < 4 ? 4 + i : 8) : i, cls = i < 4 ? i : 3;
+        const bf16x8 xf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xl + poff[i] * 4));
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[m][cls] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wl + m * WB + (blk * 64 + lane) * 8)), xf,
+                                                                acc[m][cls], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: D row = ci (4 lk + r), D col = j (lj): fine columns 2 (cw0 + j) + {0, 1} of rows 2 (ch0 + bh) + {0, 1}, slice 2 cd0 + pd
+  const int id = 2 * cd0 + pd, iw = 2 * (cw0 + lj);
+  unsigned short* __restrict__ const dxh = reinterpret_cast<unsigned short*>(a.dx);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ci = m0 + 16 * m + 4 * lk + r;
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        const int ih = 2 * (ch0 + bh) + ph;
+        if (ci < a.Cin && id < a.D && ih < a.H && iw < a.W) {
+          unsigned* __restrict__ const p = reinterpret_cast<unsigned*>(dxh + (size_t)ci * V + ((size_t)id * a.H + ih) * a.W + iw);
+          float v0 = acc[m][ph * 2 + 0][r], v1 = acc[m][ph * 2 + 1][r];
+          if (a.accumulate) {
+            const unsigned old = *p;
+            v0 += __builtin_bit_cast(float, old << 16); v1 += __builtin_bit_cast(float, old & 0xffff0000u);
+          }
+          *p = pack_bf16(v0, v1);
+        }
+      }
+    }
+}
+
 }  // namespace
 
 // Packed-weight scratch: one slot per (weight tensor, direction, shape, kernel family), carved from 64 MB chunks and kept for the life of
@@ -970,4 +1138,25 @@ int dpi_conv_bf16_s2_run(const dpi_conv_desc* d, const float* x, const float* ch
   else if (mt == 2) conv_bf16_s2_kernel<2><<<grid, 256, 0, st>>>(a);
   else conv_bf16_s2_kernel<1><<<grid, 256, 0, st>>>(a);
   return dpi_check_launch("conv_bf16_s2");
+}
+
+// ---- stride-2 backward-data on the bf16 MFMA (conv_bf16_s2_bwd_kernel): bf16 dy and dx, bf16 arithmetic, W a multiple of 8 ----------------
+bool dpi_conv_bf16_s2_bwd_usable(const dpi_conv_desc* d) {
+  return d->precision == 1 && d->k == 3 && d->kd == 3 && d->stride == 2 && (d->io & DPI_IO_DY_BF16) && (d->io & DPI_IO_DX_BF16) && (d->W & 7) == 0
+         && (size_t)d->D * d->H * d->W < ((size_t)1 << 30) && (size_t)cdiv(d->Cin, 16) * cdiv(d->Cout, 8) * 9 * 512 * 2 * 4 <= kPackMaxSlot;
+}
+int dpi_conv_bf16_s2_bwd_run(const dpi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, hipStream_t st) {
+  const int mt = d->Cin > 16 ? 2 : 1;
+  const int tiles_pad = cdiv(d->Cin, 16 * mt) * mt;
+  unsigned short* const wpk = static_cast<unsigned short*>(dpi_pack_slot(w, 3, d->Cin, d->Cout, 33 | (mt << 6),
+                                                                         (size_t)tiles_pad * cdiv(d->Cout, 8) * 9 * 512 * sizeof(unsigned short)));
+  if (!wpk) return DPI_E_LAUNCH;
+  conv_bf16_s2_bwd_pack_kernel<<<dim3(cdiv(d->Cout, 8), tiles_pad), 256, 0, st>>>(w, d->Cin, d->Cout, wpk, mt);
+  S2BArgs a{dy, dx, wpk, d->Cin, d->Cout, d->D, d->H, d->W, 0, 0, 0, cdiv(d->D, 2), cdiv(d->H, 4), cdiv(d->W, 32), cdiv(d->Cin, 16 * mt), accumulate};
+  dpi_conv_out_dims(d, &a.Do, &a.Ho, &a.Wo);
+  const int ntiles = a.ntd * a.nth * a.ntw;
+  const dim3 grid(8 * cdiv(ntiles, 8) * a.ny);
+  if (mt == 2) conv_bf16_s2_bwd_kernel<2><<<grid, 256, 0, st>>>(a);
+  else conv_bf16_s2_bwd_kernel<1><<<grid, 256, 0, st>>>(a);
+  return dpi_check_launch("conv_bf16_s2_bwd");
 }

@@ -477,6 +477,8 @@ bool dpi_conv_bf16_usable(const dpi_conv_desc* d, bool flip);
 // conv_bf16_mfma.hip: 3x3x3 stride-2 forward, bf16 x and y, bf16 arithmetic
 bool dpi_conv_bf16_s2_usable(const dpi_conv_desc* d);
 int dpi_conv_bf16_s2_stat_blocks(const dpi_conv_desc* d);
+bool dpi_conv_bf16_s2_bwd_usable(const dpi_conv_desc* d);
+int dpi_conv_bf16_s2_bwd_run(const dpi_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, hipStream_t st);
 int dpi_conv_bf16_s2_run(const dpi_conv_desc* d, const float* x, const float* chain, const float* w, const float* bias, float* y, double* partials,
                          hipStream_t st);
 int dpi_conv_bf16_stat_blocks(const dpi_conv_desc* d);
@@ -624,6 +626,8 @@ extern "C" int dpi_conv_bwd_data_ws(const dpi_conv_desc* d, const float* dy, con
   DPI_REQUIRE(ws || ws_floats == 0, "conv_bwd_data: workspace size without a workspace");
   hipStream_t st = (hipStream_t)stream;
   if (d->stride == 1) return conv_run(d, dy, nullptr, w, nullptr, dx, nullptr, true, accumulate, ws, ws_floats, st);
+  // bf16 tensors in the bf16 arithmetic mode: parity-class GEMMs on the bf16 MFMA (8-byte pieces of dy, dword stores of dx)
+  if (dpi_conv_bf16_s2_bwd_usable(d) && ((uintptr_t)dy & 7) == 0 && ((uintptr_t)dx & 3) == 0) return dpi_conv_bf16_s2_bwd_run(d, dy, w, dx, accumulate, st);
   if (d->Cin >= g_mfma_min_cout) return dpi_conv_bwd_data_s2_mfma_run(d, dy, w, dx, accumulate, st);
   int Do, Ho, Wo;
   dpi_conv_out_dims(d, &Do, &Ho, &Wo);
