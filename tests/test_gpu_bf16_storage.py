@@ -70,6 +70,10 @@ CONV_IO = [
     (212, 71, (4, 8, 8), 3, 1),       # input-channel split (workspace) + splitk_reduce_kernel storing bf16
     (25, 25, (16, 32, 32), 3, 2),     # stride 2: conv_mfma<..,S=2>, conv_bwd_data_s2_mfma; backward-weight: conv_bf16_bww_s2_kernel<2> in bf16 mode (W % 16 == 0)
     (40, 13, (7, 9, 48), 3, 2),       # ... odd depth / height (rows past the end of x), one output tile, three 16-channel input tiles, ragged last octet chunk
+    (1, 20, (4, 6, 16), 3, 2),        # stride-2 bf16 kernels (forward / backward-data / backward-weight): one input channel, W = 16 (a single 16-column output tile, 8 octets per row)
+    (33, 7, (5, 8, 64), 3, 2),        # ... 33 = 4 groups + 1 channel, 7 output channels (one ragged 16-row tile), W = 64
+    (16, 64, (2, 2, 32), 3, 2),       # ... four output tiles per workgroup (forward MT = 4), D = H = 2 (one output slice / row)
+    (70, 70, (3, 5, 24), 3, 2),       # ... W = 24: forward and backward-data (W % 8 == 0) on the bf16 MFMA, backward-weight (needs W % 16 == 0) on the fp32 kernel
     (51, 51, (9, 11, 13), 3, 2),      # stride 2, odd sizes
     (3, 5, (6, 6, 6), 3, 2),          # VALU stride-2 kernels (few channels)
     (64, 25, (16, 16, 32), 1, 1),     # 1x1x1 MFMA forward / backward-data / backward-weight
