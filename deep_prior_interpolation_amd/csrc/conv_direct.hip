@@ -522,7 +522,7 @@ extern "C" int dpi_conv_fwd_stat_blocks(const dpi_conv_desc* d) {
 // which launches take the fp32-MFMA stencil path of conv_mfma.hip (the order of the tests in conv_run)
 static bool takes_mfma_path(const dpi_conv_desc* d, bool flip) {
   const int cout = flip ? d->Cin : d->Cout;
-  if (dpi_conv_bf16_usable(d, flip) || dpi_conv_q4_usable(d, flip)) return false;
+  if (dpi_conv_bf16_usable(d, flip) || dpi_conv_q4_usable(d, flip) || (!flip && dpi_conv_bf16_s2_usable(d))) return false;
   return d->k == 3 && cout >= g_mfma_min_cout && (d->stride == 1 || !flip);
 }
 
