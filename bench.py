@@ -90,13 +90,13 @@ PRECISION = "fp32"
 WGRAD_OVERLAP = os.environ.get("DPI_BENCH_WGRAD_OVERLAP", "1") == "1"     # weight gradients on a side stream (eager, patches >= 2^20 voxels)
 # the metric's second half; numbers from tests/test_gpu_snr_parity.py on the committed reference recordings
 SNR_STATEMENT = ("SNR(out_best) HIP vs the reference's own Interpolator, same volume / mask / hyper-parameters: "
-                 "+0.08 dB +- 0.39 (2 s.e., n = 6 + 7) at 128x64x64 on the notebook-like stand-in, 1200 iterations — the smallest volume that "
-                 "runs the bench patch's kernel variants (tests/golden/snr_mid_128x64x64.npz: reference 23.40 +- 0.41 dB, HIP 23.48 +- 0.29; mean "
-                 "trajectories within 0.16 dB at iterations 100..1199); +0.22 dB +- 0.34 (2 s.e., n = 48 + 48) at 48x32x32, 1000 iterations "
+                 "-0.04 dB +- 0.39 (2 s.e., n = 6 + 9) at 128x64x64 on the notebook-like stand-in, 1200 iterations — the smallest volume that "
+                 "runs the bench patch's kernel variants (tests/golden/snr_mid_128x64x64.npz: reference 23.52 +- 0.46 dB, HIP 23.48 +- 0.29; mean "
+                 "trajectories within 0.32 dB at iterations 100..1199); +0.22 dB +- 0.34 (2 s.e., n = 48 + 48) at 48x32x32, 1000 iterations "
                  "(tests/golden/snr_spread.npz); bf16 storage at 48x32x32: +0.18 dB +- 0.49.  All within the reference's own seed-to-seed spread "
-                 "(0.4-0.9 dB), not resolvable to 0.1 dB.  At 256x128x128 the head of ONE reference run (>= 400 iterations, "
-                 "tests/golden/snr_bench_head_256x128x128.npz) leaves 0 dB at iteration 68 (HIP 59 / 67) and trails the HIP runs by 2.6 / 1.8 dB at "
-                 "iterations 220 / 300 (HIP's own seed spread there: 1.1 dB); complete 3000-iteration HIP runs reach 24.5-25.0 dB "
+                 "(0.4-0.9 dB), not resolvable to 0.1 dB.  At 256x128x128 the head of ONE reference run (525 iterations, "
+                 "tests/golden/snr_bench_head_256x128x128.npz) leaves 0 dB at iteration 68 (HIP 59 / 67) and trails the HIP runs by 2.6 / 1.8 / 0.9 / 1.5 dB at "
+                 "iterations 220 / 300 / 400 / 500 (HIP's own seed spread at 220: 1.1 dB); complete 3000-iteration HIP runs reach 24.5-25.0 dB "
                  "(profiles/r03, profiles/r04 full_run_*.json)")
 
 

@@ -162,9 +162,9 @@ def test_mid_size_snr_matches_the_reference_at_big_tile_size():
     4x8x32 / 4x4x32 MFMA tiles and the 4x4x1 few-channel kernel need >= 512 tiles: 128x64x64 is the smallest such volume), on the
     notebook-like stand-in (`u.hyperbolic_volume`, std of the coarse data 4.47 as in proof_of_concept_3D.ipynb:355,362).
     tests/golden/snr_mid_128x64x64.npz: the reference's own Interpolator (oracle/make_snr_spread.py --mid, imported from
-    /root/reference; 2 CPU threads per seed, ~2.7 h per seed), seeds 0..2 (round 3) + 3, 4, 7, 8 and whichever of 5, 6, 9, 10 had
-    finished when round 4 ended (the file says), 1200 Adam iterations, loss / SNR / PCORR history.  The reference's own seed-to-seed
-    standard deviation here: 2.3 dB at iteration 100, 0.7 at 220, 0.5 at 300, 0.3 from 500 on; SNR(out_best) 23.4 +- 0.4 dB.
+    /root/reference; 2 CPU threads per seed, ~2.7 h per seed), seeds 0..2 (round 3) + 3, 4, 5, 7, 8, 9 (round 4; 6 and 10
+    had just started when it ended), 1200 Adam iterations, loss / SNR / PCORR history.  The reference's own seed-to-seed
+    standard deviation here: 2.3 dB at iteration 100, 0.7 at 220, 0.5 at 300, 0.3 from 500 on; SNR(out_best) 23.5 +- 0.5 dB.
     Here: the HIP path on the same volume, mask and hyper-parameters, seeds 0..5 (bit-identical initial weights, its own
     Philox noise).  Bars fixed a priori from the (48,32,32) protocol, where the reference's seed-to-seed standard deviation of
     SNR(out_best) is 0.88 dB: mean trajectory within max(3 s.e., 1 dB) of the reference's at every checkpoint, mean SNR(out_best)
@@ -204,14 +204,14 @@ def test_mid_size_snr_matches_the_reference_at_big_tile_size():
 def test_head_of_the_run_at_bench_geometry_against_the_reference():
     """The bench geometry itself (256x128x128, BASELINE configs[1]) against the REFERENCE: tests/golden/snr_bench_head_256x128x128.npz is
     the head of a 3000-iteration run of the reference's Interpolator on the notebook-like stand-in (oracle/make_snr_spread.py --mid
-    256 128 128: 3 CPU threads, ~57 s per iteration, recorded in the background of round 4 as far as the round lasted — >= 400
-    iterations of seed 0: off 0 dB at iteration 68, 4.9 / 13.1 / 15.4 / 17.7 dB at 100 / 220 / 300 / 400).  Here: the HIP path on the
+    256 128 128: 3 CPU threads, ~57 s per iteration, recorded in the background of round 4 as far as the round lasted — 525
+    iterations of seed 0: off 0 dB at iteration 68, 4.9 / 13.1 / 15.4 / 17.1 / 17.4 dB at 100 / 220 / 300 / 400 / 500).  Here: the HIP path on the
     same volume and mask, seeds 0 and 1, for as many iterations.  One reference seed pins no distribution; the bars come from the
     reference's seed-to-seed spread at 128x64x64 (previous test: s.d. 2.3 dB at iteration 100, 0.7 at 220, 0.5 at 300) and the HIP runs'
     own at this size (1.1 dB at 220 over four runs): the plateau ends within a factor 2.5 of the reference's iteration either way, the
     mean of the two HIP runs stays within 4.5 dB of the reference at iteration 220 and within 3 dB from 300 on.  Recorded: plateau ends
-    at 68 (reference) / 59, 67 (HIP); HIP 7.8 / 15.7 / 17.2 dB at 100 / 220 / 300 — this reference seed trails the HIP runs by 2.6 dB at
-    220 and 1.8 dB at 300 (about 50 iterations), where the two agree to 0.1-0.2 dB at 128x64x64 with 6 / 7 seeds; one seed cannot tell a
+    at 68 (reference) / 59, 67 (HIP); HIP 7.8 / 15.7 / 17.2 / 18.0 / 18.9 dB at 100 / 220 / 300 / 400 / 500 — this reference seed trails the HIP
+    runs by 2.6 dB at 220, 1.8 at 300, 0.9 at 400, 1.5 at 500, where the two agree to 0.3 dB or better at 128x64x64 with 6 / 9 seeds; one seed cannot tell a
     seed effect from a size effect, so the bars stay wide and the number is reported as it is."""
     import hashlib
     from deep_prior_interpolation_amd import utils as u
