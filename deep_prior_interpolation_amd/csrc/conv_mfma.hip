@@ -49,6 +49,10 @@ struct MArgs {
   // storage type of the input tensor(s) x / x2 and of the output y in HBM: 1 = bf16, 0 = fp32 (dpi_conv_desc.io; common.h).
   // A split launch (split_cps > 0) writes fp32 partials into the workspace whatever y is; splitk_reduce_kernel stores y.
   int xb, yb;
+  // > 0: 1-D grid of 8 * ceil(ntiles / 8) * ny workgroups; XCD x (= workgroup id % 8) walks ITS contiguous tile range with the ny
+  // output-channel tiles of a spatial tile back to back — they read the same input tile (and second input), which as the slow grid
+  // dimension they fetched from HBM once per channel tile (round 4, as conv_bf16_mfma.hip).  0: the 2-D grid (persistent variants).
+  int ny;
 };
 
 // Tile geometry.  A wave owns NR output rows x NH 16-voxel column blocks; the 4 waves of a workgroup own
@@ -202,9 +206,19 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lk = lane >> 4, lj = lane & 15;
-  const int n0 = blockIdx.y * 16;
-  const size_t V = (size_t)a.D * a.H * a.W;
   const int ntiles = a.ntd * a.nth * a.ntw;
+  int vt0 = blockIdx.x, ytile = blockIdx.y;
+  if constexpr (!PERSIST) {
+    if (a.ny > 0) {
+      const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+      const int i = j / a.ny;
+      ytile = j - i * a.ny;
+      if (i >= q8 + (xcd < r8 ? 1 : 0)) return;               // past this XCD's tile range (whole workgroup, before any barrier)
+      vt0 = i * 8 + xcd;                                       // xcd_tile() maps it to tile i of XCD xcd's range
+    }
+  }
+  const int n0 = ytile * 16;
+  const size_t V = (size_t)a.D * a.H * a.W;
   const int Do = (a.D + 2 * PD - KD) / G::SD + 1, Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
   const size_t Vo = (size_t)Do * Ho * Wo;
 #ifdef DPI_TRACE
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(256, WPE) void conv_mfma_kernel(MArgs a) {
   float* __restrict__ const ybase = a.y + (size_t)blockIdx.z * a.Cout * Vo;      // (blockIdx.z > 0 only in split launches: fp32 workspace)
   int goff[G::E], loff[G::E];
   float wr[TAPS], wn[9], sr[4][G::E];
-  int vt = blockIdx.x, tile_id, od0, oh0, ow0;
+  int vt = vt0, tile_id, od0, oh0, ow0;
   tile_origin(vt, tile_id, od0, oh0, ow0);
   tile_slots<G>(tid, od0 * G::SD - PD, oh0 * S - 1, ow0 * S - 1, a.D, a.H, a.W, goff, loff);
   stage_load<G>(sr, a.x, a.Cin, V, c_lo, goff, a.xb);
@@ -1159,9 +1173,17 @@ int dpi_mfma_tiles(const dpi_conv_desc* d, int nr, int nh, int* ntd, int* nth, i
 }
 
 template <int KD, bool FLIP, bool IOB = false>
-static void launch_variant(const MArgs& a, int nr, int nh, int stride, dim3 grid, hipStream_t st) {
+static void launch_variant(const MArgs& a_in, int nr, int nh, int stride, dim3 grid_in, hipStream_t st) {
   if constexpr (!IOB) {
-    if (a.xb || a.yb) { launch_variant<KD, FLIP, true>(a, nr, nh, stride, grid, st); return; }
+    if (a_in.xb || a_in.yb) { launch_variant<KD, FLIP, true>(a_in, nr, nh, stride, grid_in, st); return; }
+  }
+  // one-tile-per-workgroup variants: channel tiles of a spatial tile back to back (MArgs::ny); the persistent variants keep the 2-D grid
+  const bool persistent = stride == 1 && nr == 8 && a_in.Cin > 8;
+  MArgs a = a_in;
+  dim3 grid = grid_in;
+  if (!persistent && grid_in.y > 1) {
+    a.ny = (int)grid_in.y;
+    grid = dim3(8 * ((grid_in.x + 7) / 8) * grid_in.y, 1, grid_in.z);
   }
   if (stride == 2) {
     if constexpr (!FLIP) {
