@@ -94,9 +94,9 @@ SNR_STATEMENT = ("SNR(out_best) HIP vs the reference's own Interpolator, same vo
                  "runs the bench patch's kernel variants (tests/golden/snr_mid_128x64x64.npz: reference 23.52 +- 0.46 dB, HIP 23.48 +- 0.29; mean "
                  "trajectories within 0.32 dB at iterations 100..1199); +0.22 dB +- 0.34 (2 s.e., n = 48 + 48) at 48x32x32, 1000 iterations "
                  "(tests/golden/snr_spread.npz); bf16 storage at 48x32x32: +0.18 dB +- 0.49.  All within the reference's own seed-to-seed spread "
-                 "(0.4-0.9 dB), not resolvable to 0.1 dB.  At 256x128x128 the head of ONE reference run (525 iterations, "
-                 "tests/golden/snr_bench_head_256x128x128.npz) leaves 0 dB at iteration 68 (HIP 59 / 67) and trails the HIP runs by 2.6 / 1.8 / 0.9 / 1.5 dB at "
-                 "iterations 220 / 300 / 400 / 500 (HIP's own seed spread at 220: 1.1 dB); complete 3000-iteration HIP runs reach 24.5-25.0 dB "
+                 "(0.4-0.9 dB), not resolvable to 0.1 dB.  At 256x128x128 the head of ONE reference run (625 iterations, "
+                 "tests/golden/snr_bench_head_256x128x128.npz) leaves 0 dB at iteration 68 (HIP 59 / 67) and trails the HIP runs by 2.6 / 1.8 / 0.9 / 1.5 / 1.4 dB at "
+                 "iterations 220 / 300 / 400 / 500 / 599 (HIP's own seed spread at 220: 1.1 dB); complete 3000-iteration HIP runs reach 24.5-25.0 dB "
                  "(profiles/r03, profiles/r04 full_run_*.json)")
 
 

@@ -204,7 +204,7 @@ def test_mid_size_snr_matches_the_reference_at_big_tile_size():
 def test_head_of_the_run_at_bench_geometry_against_the_reference():
     """The bench geometry itself (256x128x128, BASELINE configs[1]) against the REFERENCE: tests/golden/snr_bench_head_256x128x128.npz is
     the head of a 3000-iteration run of the reference's Interpolator on the notebook-like stand-in (oracle/make_snr_spread.py --mid
-    256 128 128: 3 CPU threads, ~57 s per iteration, recorded in the background of round 4 as far as the round lasted — 525
+    256 128 128: 3 CPU threads, ~57 s per iteration, recorded in the background of round 4 as far as the round lasted — 625
     iterations of seed 0: off 0 dB at iteration 68, 4.9 / 13.1 / 15.4 / 17.1 / 17.4 dB at 100 / 220 / 300 / 400 / 500).  Here: the HIP path on the
     same volume and mask, seeds 0 and 1, for as many iterations.  One reference seed pins no distribution; the bars come from the
     reference's seed-to-seed spread at 128x64x64 (previous test: s.d. 2.3 dB at iteration 100, 0.7 at 220, 0.5 at 300) and the HIP runs'
