@@ -15,7 +15,7 @@ class DpiError(RuntimeError):
     pass
 
 
-ABI_VERSION = 403      # include/dpi_hip.h: dpi_conv_desc starts with its own size (300); dpi_conv_fwd_ws / dpi_conv_bwd_data_ws (301); `io` + the *_io entry points (400); dpi_pack_* (401); dpi_pack_forget (402); dpi_join_bwd (403)
+ABI_VERSION = 404      # dpi_set_option replaces the ten dpi_set_* tuning exports (404); include/dpi_hip.h: dpi_conv_desc starts with its own size (300); dpi_conv_fwd_ws / dpi_conv_bwd_data_ws (301); `io` + the *_io entry points (400); dpi_pack_* (401); dpi_pack_forget (402); dpi_join_bwd (403)
 
 # dpi_conv_desc.io bits / the `io` masks of the *_io entry points (bf16 storage of activations, BASELINE configs[4])
 IO_X_BF16, IO_Y_BF16, IO_DY_BF16, IO_DX_BF16 = 1, 2, 4, 8
@@ -50,8 +50,6 @@ SIGNATURES = {
     "dpi_conv_desc_size": (_I, []),
     "dpi_device_info": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_Z), C.c_char_p, _I]),
     "dpi_profile_marker": (_I, [_I, _P]),
-    "dpi_set_bw_tuning": (None, [_I, _I]),
-    "dpi_set_bf16_debug": (None, [_I]),
     "dpi_conv_fwd_stat_blocks": (_I, [_DESC]),
     "dpi_conv_fwd": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P]),
     "dpi_conv_bwd_data": (_I, [_DESC, _P, _P, _P, _I, _P]),
@@ -59,17 +57,9 @@ SIGNATURES = {
     "dpi_conv_bwd_data_ws_floats": (_Z, [_DESC]),
     "dpi_conv_fwd_ws": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "dpi_conv_bwd_data_ws": (_I, [_DESC, _P, _P, _P, _I, _P, _Z, _P]),
-    "dpi_set_splitk": (None, [_I]),
     "dpi_conv_bwd_data_dual": (_I, [_DESC, _P, _P, _DESC, _P, _P, _P, _I, _P, _Z, _P]),
-    "dpi_set_dual_bwd_data": (None, [_I]),
-    "dpi_set_bw_pair": (None, [_I]),
     "dpi_conv_bwd_weight_ws_floats": (_Z, [_DESC]),
     "dpi_conv_bwd_weight": (_I, [_DESC, _P, _P, _P, _P, _P, _Z, _P]),
-    "dpi_set_mfma_min_cout": (None, [_I]),
-    "dpi_set_bwd_weight_mfma_min_cout": (None, [_I]),
-    "dpi_set_fewco_mfma": (None, [_I]),
-    "dpi_set_q4": (None, [_I, _I]),
-    "dpi_set_q4_debug": (None, [_I]),
     "dpi_stat_blocks": (_I, [_I, _Z]),
     "dpi_channel_stats": (_I, [_P, _P, _I, _Z, _P, _P]),
     "dpi_bn_finalize": (_I, [_P, _I, _I, _Z, _P, _P, _F, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P]),
@@ -128,6 +118,7 @@ SIGNATURES = {
     "dpi_noise_add_io": (_I, [_P, _Z, _F, _U64, _P, _P, _U, _P]),
     "dpi_noise_add_regen_io": (_I, [_Z, _F, _U64, _U64, _F, _U64, _P, _P, _U, _P]),
     # ABI 401: the packed-weight scratch of the bf16 stencil kernel
+    "dpi_set_option": (_I, [C.c_char_p, _I]),              # ABI 404: the one switchboard for tests / tools (never called by the product path)
     "dpi_pack_scratch_bytes": (_Z, []),
     "dpi_pack_release": (_I, []),
     "dpi_pack_forget": (_I, [_P]),
@@ -164,6 +155,8 @@ def load():
     if lib.dpi_version() < ABI_VERSION or lib.dpi_conv_desc_size() != C.sizeof(ConvDesc):
         raise DpiError("libdpi_hip.so is ABI version %d with a %d-byte dpi_conv_desc; this binding needs >= %d and %d bytes (stale build? "
                        "re-run __graft_entry__.build())" % (lib.dpi_version(), lib.dpi_conv_desc_size(), ABI_VERSION, C.sizeof(ConvDesc)))
+    # tests / tools: L.set_option("bf16_debug", 8) — raises on an unknown key or a value out of range
+    lib.set_option = lambda key, value: check(lib.dpi_set_option(key.encode(), int(value)), "dpi_set_option(%s)" % key)
     _lib = lib
     return lib
 

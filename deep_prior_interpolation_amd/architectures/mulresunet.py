@@ -131,10 +131,12 @@ class SkipConcat(Concat):
             if isinstance(rp, ResPath) and rp._fusable() and isinstance(mods[-1], hnn.Upsample):
                 # the ResPath half only needs x: started on the branch stream before the deeper U runs (ops.skip_begin; None = serial)
                 pre = ops.skip_begin(x, rp, rp.act.negative_slope, _deep_channels(mods[:-1])) if x.ndim == 5 else None
-                xs = ops.skip_tap(x) if pre is not None else x
-                deep = deeper(x, stop_before_last=True)
+                # the two gradients of x (ResPath, stride-2 layer of the deeper U) meet inside the stride-2 layer's backward-data (ops.FanIn)
+                fan = ops.FanIn() if (ops.FAN_IN and x.ndim == 5 and x.requires_grad) else None
+                xs = ops.skip_tap(x) if (pre is not None or fan is not None) else x
+                deep = deeper(x, stop_before_last=True, fan=fan)
                 if deep.ndim == 5:
-                    return ops.skip_join(xs, deep, rp, rp.act.negative_slope, mods[-1].mode, pre)
+                    return ops.skip_join(xs, deep, rp, rp.act.negative_slope, mods[-1].mode, pre, fan)
                 return ops.concat_crop([rp(x), mods[-1](deep)])
         return super().forward(x)
 
@@ -153,16 +155,16 @@ class DownPath(Seq):
     """The `deeper` branch: stride-2 conv [-> BN] -> act -> dropout -> block -> [inner] -> upsample.  Same children and
     names as a plain Seq; only the conv -> BN -> LeakyReLU head (3-D) is executed as one fused op."""
 
-    def forward(self, x, stop_before_last=False):
+    def forward(self, x, stop_before_last=False, fan=None):
         mods = list(self._modules.values())
-        return self._run(mods[:-1] if stop_before_last else mods, x)
+        return self._run(mods[:-1] if stop_before_last else mods, x, fan)
 
-    def _run(self, mods, x):
+    def _run(self, mods, x, fan=None):
         if (len(mods) >= 3 and isinstance(mods[1], (hnn.BatchNorm3d, hnn.BatchNorm2d)) and isinstance(mods[2], hnn.LeakyReLU)
                 and isinstance(mods[0], nn.Sequential)):
             conv_m, bn, act = mods[0][0], mods[1], mods[2]
             x = ops.conv_bn_act(x, conv_m.weight, conv_m.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                bn.num_batches_tracked, conv_m._s, act.negative_slope)
+                                bn.num_batches_tracked, conv_m._s, act.negative_slope, fan)
             mods = mods[3:]
         for m in mods:
             x = m(x)

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/dpi_hip.h"
+#include "dpi_hip_internal.h"
 
 #define DPI_WAVE 64
 

@@ -114,7 +114,14 @@ class Interpolator:
         and prepared for the data-forgetting term (main.py:59-97)."""
         a = self.args
         philox_z = (None,)
-        if a.noise_dist != "n":
+        self._z_cpu = None
+        if self.noise_source() == "torch_cpu":
+            # parity mode: the reference's own draw (main.py:61-64: get_noise(...).type(dtype); input_ *= noise_std) from torch's CPU generator
+            z = u.get_noise((1, a.inputdepth) + self.img.shape[:-1], a.noise_dist).float()
+            z *= a.noise_std
+            self._z_cpu = z
+            z = z.to(self.device)
+        elif a.noise_dist != "n":
             z = u.get_noise((1, a.inputdepth) + self.img.shape[:-1], a.noise_dist).to(self.device) * a.noise_std
         else:
             z = torch.empty((1, a.inputdepth) + self.img.shape[:-1], dtype=torch.float32, device=self.device)
@@ -139,6 +146,8 @@ class Interpolator:
             self.add_data_ = data_
             self.add_data_weight = np.logspace(0, -4, a.data_forgetting_factor)
         self.input_ = z
+        if self._z_cpu is not None and (a.filter_noise_with_wavelet or (a.lowpass_fs and a.lowpass_fc)):
+            self._z_cpu = z.float().cpu()                       # the perturbation below is added to the FILTERED z (main.py:148-150)
         # z is still the plain Philox fill: the per-iteration perturbation COULD re-draw it instead of reading it (dpi_noise_add_regen_io,
         # DPI_Z_REGEN=1).  Off by default — measured slower: a second Philox4x32-10 + Box-Muller per four elements makes the pass ALU-bound
         # (0.45 ms at 256x128x128 x 64 channels against 0.36-0.41 ms for reading z: 134 M normal deviates per iteration either way)
@@ -148,11 +157,13 @@ class Interpolator:
     # ------------------------------------------------------------------------------------------
     def perturbed_input(self):
         """input = z + reg_noise_std * N(0,1), fresh every iteration (main.py:148-150)."""
+        if self.noise_source() == "torch_cpu":
+            return self._perturbed_input_torch_cpu()
         if self.args.reg_noise_std <= 0:
             return self.input_
         # (bf16 storage: the perturbed input is the first activation the net reads — 64 channels at full resolution — and is written as
         #  bf16 straight away; z itself stays fp32)
-        bf = ops.STORAGE_BF16 and self.input_.ndim == 5
+        bf = ops.storage_bf16() and self.input_.ndim == 5
         out = torch.empty_like(self.input_, dtype=torch.bfloat16) if bf else torch.empty_like(self.input_)
         self._noise_step += 1
         zp = getattr(self, "_z_philox", None)
@@ -166,22 +177,40 @@ class Interpolator:
                                                 _lib.STORE_FWD_BF16 if bf else 0, _lib.stream()), "dpi_noise_add")
         return out
 
+    def noise_source(self):
+        return getattr(self.args, "noise_source", "philox")
+
+    def _perturbed_input_torch_cpu(self):
+        """--noise_source torch_cpu (parity mode): the reference's draws of one iteration in the reference's order, from torch's CPU generator —
+        main.py:143-145: with --param_noise (ON by default in the CLI) one normal_() per 4-D / 5-D parameter, whose result the
+        reference discards (it rebinds a local) but which moves the generator; main.py:148-150: input = z + reg_noise_std * z.clone().normal_()
+        in fp32 on the host — then uploaded.  ~3 s of host time per iteration at 256x128x128 x 64 channels: a parity tool, not the fast path."""
+        a = self.args
+        if a.param_noise:
+            for p in self.net.parameters():
+                if p.ndim in (4, 5):
+                    torch.empty(p.shape, dtype=torch.float32).normal_()
+        inp = self._z_cpu.clone()
+        if a.reg_noise_std > 0:
+            inp += a.reg_noise_std * inp.clone().normal_()
+        inp = inp.to(self.device)
+        return inp.to(torch.bfloat16) if (ops.storage_bf16() and inp.ndim == 5) else inp
+
     def _to_numpy_out(self, out_):
         """(1,1,T,X,Y) -> (T,X,Y) ; (1,C,H,W) -> (H,W,C)  (main.py:175-176)."""
         return u.torch_to_np(out_, True) if out_.ndim > 4 else u.torch_to_np(out_, False)[0].transpose((1, 2, 0))
 
-    def apply_precision(self):
-        """--precision of THIS Interpolator becomes the arithmetic mode of the convolutions launched from here on (ops.PRECISION is
-        read when a layer builds its descriptor).  Called at the top of every iteration, eager or captured, so that the mode never
-        depends on which Interpolator ran before in the process (DPI_PRECISION in the environment is a tools-only override of the
-        default)."""
+    def precision_scope(self):
+        """--precision of THIS Interpolator as an ops.mode_scope: the arithmetic mode of the convolutions and the storage type of the activations of
+        everything built inside it, on this host thread only (round 6; rounds 2-5 flipped module globals of `ops` at the top of every iteration).
+        Every iteration, eager or captured, runs inside one — so the mode never depends on which Interpolator ran before in the process, and two
+        Interpolators of different --precision cannot disturb each other whichever way they are interleaved.  DPI_PRECISION / DPI_STORAGE in the
+        environment are tools-only overrides of the fp32 default: an fp32 Interpolator leaves that half to the process default.
+        bf16 STORAGE of the activations (BASELINE configs[4]) where every node of the net is a fused 3-D node that takes it (storage_bf16_ok)."""
         prec = getattr(self.args, "precision", "fp32")
-        if prec != "fp32" or "DPI_PRECISION" not in os.environ:
-            ops.set_precision(prec)
-        # bf16 STORAGE of the activations (BASELINE configs[4]) where every node of the net is a fused 3-D node that takes it
-        # (DPI_STORAGE in the environment is, like DPI_PRECISION, a tools-only override of the fp32 default: an fp32 Interpolator leaves it alone)
-        if prec != "fp32" or "DPI_STORAGE" not in os.environ:
-            ops.set_storage("bf16" if (prec == "bf16" and self.storage_bf16_ok()) else "fp32")
+        p = prec if (prec != "fp32" or "DPI_PRECISION" not in os.environ) else None
+        st = ("bf16" if (prec == "bf16" and self.storage_bf16_ok()) else "fp32") if (prec != "fp32" or "DPI_STORAGE" not in os.environ) else None
+        return ops.mode_scope(p, st)
 
     def wants_weight_grad_overlap(self):
         """Weight gradients on side streams next to the backward-data chain (and with them the once-per-step join and the ResPath branch
@@ -213,7 +242,14 @@ class Interpolator:
         return ok
 
     def optimization_loop(self, net_input=None):
-        self.apply_precision()
+        try:
+            with self.precision_scope():
+                return self._optimization_loop(net_input)
+        except BaseException:
+            ops.abort_iteration()          # streams joined, per-iteration state of ops forgotten: a later bare backward() joins per node again
+            raise
+
+    def _optimization_loop(self, net_input=None):
         ops.begin_iteration()
         input_ = self.perturbed_input() if net_input is None else net_input
         if self.iiter < self.args.data_forgetting_factor:       # main.py:153-155
@@ -227,14 +263,14 @@ class Interpolator:
         reg = self.regularization(out_, total_loss)          # None, or (weight tensor / float, reg loss) of a subclass / add-on
         if reg is None:
             total_loss.backward()
-            ops.finish_backward()
+            ops.finish_backward(self._grad_params())
             l, s, p = metrics[:3].tolist()          # one read-back for loss, snr, pcorr
             self.history.append((l, s, p))
         else:
             eps, reg_loss = reg
             total = total_loss + eps * reg_loss
             total.backward()
-            ops.finish_backward()
+            ops.finish_backward(self._grad_params())
             main_l, s, p = metrics[:3].tolist()
             l, r = float(total.item()), float(reg_loss.item())
             self.history.append((l, main_l, r, s, p))           # HistoryReg layout (main_pocs.py:198-202)
@@ -247,6 +283,10 @@ class Interpolator:
                                  + "_output%s.npy" % str(self.iiter).zfill(self.zfill)), self._to_numpy_out(out_))
         self.iiter += 1
         return l
+
+    def _grad_params(self):
+        """The parameters ops.finish_backward() checks the deferred gradients against (only when a side / branch stream ran: big patches)."""
+        return self.optimizer._params if (ops._deferred and self.optimizer is not None) else None
 
     def regularization(self, out_, main_loss):
         """Extra loss term hook.  The base path has none.  With --aa_weight > 0 (2-D / 2.5-D sections) the anti-aliasing add-on
@@ -296,10 +336,12 @@ class Interpolator:
             # on configs[4], 30 iterations per patch: 160-210 ms per iteration with the capture, 113 ms eager)
             large = int(np.prod(self.img.shape[:-1])) >= (1 << 20)
             mode = "eager" if (net_inputs is not None or a.save_every is not None or a.epochs < 3 or self.has_regularizer()
-                               or a.data_forgetting_factor != 0 or big or (large and a.epochs < 1000)) else "graph"
+                               or a.data_forgetting_factor != 0 or self.noise_source() != "philox" or big or (large and a.epochs < 1000)) else "graph"
         self.optimizer = FusedAdam(self.net.parameters(), lr=a.lr)
         ops.set_weight_grad_overlap(big, in_graph=(mode == "graph" and big))
         start = time()
+        if mode == "graph" and self.noise_source() != "philox":
+            raise ValueError("--noise_source torch_cpu draws on the host every iteration: it cannot be captured (mode='eager')")
         if mode == "graph":
             self._optimize_graph(verbose, check_every)
         else:
@@ -329,6 +371,8 @@ class Interpolator:
         stream is synchronised before the capture and the capture is opened with CUDAGraph.capture_begin() directly (torch.cuda.graph()
         would synchronise the whole device, collect garbage and empty the allocator's cache first)."""
         a = self.args
+        if self.noise_source() != "philox":
+            raise ValueError("--noise_source torch_cpu draws on the host every iteration: it cannot be captured into a graph")
         L = _lib.load()
         dev = self.device
         if self.optimizer is None:
@@ -347,13 +391,16 @@ class Interpolator:
         kind = self.loss_kind
 
         def one_iteration():
-            self.apply_precision()
+            with self.precision_scope():
+                _one_iteration()
+
+        def _one_iteration():
             ops.begin_iteration()
             opt.zero_grad()
             out_ = self.net(self.perturbed_input())
             loss, metrics = ops.masked_loss(out_, self.img_, self.mask_, kind)
             loss.backward()
-            ops.finish_backward()
+            ops.finish_backward(self._grad_params())
             opt.step()                                   # skipped on the device once `active` is 0
             if self._g_best is None:
                 self._g_best = torch.empty_like(out_)
@@ -419,6 +466,7 @@ class Interpolator:
         """True when optimize(mode='auto') would take the hipGraph path for the loaded patch."""
         a = self.args
         return not (a.save_every is not None or a.epochs < 3 or a.data_forgetting_factor != 0 or self.has_regularizer()
+                    or self.noise_source() != "philox"
                     or int(np.prod(self.img.shape[:-1])) >= (1 << 20))
 
     # ------------------------------------------------------------------------------------------

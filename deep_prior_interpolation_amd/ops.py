@@ -6,6 +6,7 @@ patch at a time, main.py:131-135), layout (1, C, [D,] H, W) contiguous.
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -30,18 +31,55 @@ def _req(t, name, act=False):
 # ConvBnActFn) allocate their forward tensors (R, S, t, y, cat) AND the gradients of those as torch.bfloat16; the kernels widen on load and
 # round to nearest-even on store (dpi_conv_desc.io, the *_io entry points), arithmetic / BatchNorm statistics / weights / weight gradients /
 # Adam stay fp32.  A leaf convolution (the network's output layer) reads bf16 and writes fp32, so loss and metrics see fp32.
-STORAGE_BF16 = os.environ.get("DPI_STORAGE", "fp32") == "bf16"
+STORAGE_BF16 = os.environ.get("DPI_STORAGE", "fp32") == "bf16"      # process DEFAULT (tools / tests); an Interpolator's own mode is a mode_scope
+_tls = threading.local()
 
 
 def set_storage(name):
+    """Process default (tools / tests).  The product path does not call it: an Interpolator runs every iteration inside its own mode_scope."""
     global STORAGE_BF16
     if name not in ("fp32", "bf16"):
         raise ValueError("storage must be fp32 or bf16")
     STORAGE_BF16 = name == "bf16"
 
 
+class mode_scope:
+    """with mode_scope(precision, storage): the arithmetic mode / activation storage type of the fused nodes BUILT inside the block, on THIS host
+    thread only (round 6: they used to be module globals flipped per iteration, which two Interpolators of different --precision driven from two
+    threads would race on).  None leaves that half to the process default (set_precision / set_storage, DPI_PRECISION / DPI_STORAGE).  Everything
+    that depends on the mode is decided in the FORWARD of a node, on the calling thread (make_desc, act_dtype); the backward — which autograd runs on
+    its own device thread — only uses the descriptors and tensor types the forward saved.  Scopes nest; leaving one restores the previous."""
+
+    def __init__(self, precision=None, storage=None):
+        if precision is not None and precision not in _PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))
+        if storage is not None and storage not in ("fp32", "bf16"):
+            raise ValueError("storage must be fp32 or bf16")
+        self.mode = (None if precision is None else _PRECISIONS[precision], None if storage is None else storage == "bf16")
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "mode", None)
+        _tls.mode = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        _tls.mode = self.prev
+        return False
+
+
+def precision():
+    """Arithmetic mode (dpi_conv_desc.precision) of the layers built now: the innermost mode_scope of this thread, else the process default."""
+    m = getattr(_tls, "mode", None)
+    return PRECISION if (m is None or m[0] is None) else m[0]
+
+
+def storage_bf16():
+    m = getattr(_tls, "mode", None)
+    return STORAGE_BF16 if (m is None or m[1] is None) else m[1]
+
+
 def act_dtype():
-    return torch.bfloat16 if STORAGE_BF16 else torch.float32
+    return torch.bfloat16 if storage_bf16() else torch.float32
 
 
 def _bf(t):
@@ -82,12 +120,13 @@ def conv_out(n, k, s):
 # 2: "split" mode — fp32 operands split exactly into three bf16 terms, six partial products accumulated in fp32: fp32-class accuracy
 # on the bf16 matrix cores (forward / backward-data of the shapes where the kernel wins).
 # "bf16mm" is mode 1 under its round-2/3 meaning (operands only); "bf16" is the same arithmetic and, where the net supports it, bf16
-# STORAGE of the activations on top (Interpolator.apply_precision -> set_storage; round 4).
+# STORAGE of the activations on top (Interpolator.precision_scope; round 4).
 _PRECISIONS = {"fp32": 0, "bf16": 1, "bf16mm": 1, "split": 2}
 PRECISION = _PRECISIONS.get(os.environ.get("DPI_PRECISION", "fp32"), 0)
 
 
 def set_precision(name):
+    """Process default (tools / tests); see mode_scope."""
     global PRECISION
     if name not in _PRECISIONS:
         raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))
@@ -103,7 +142,7 @@ def make_desc(x, w, stride, ydt=torch.float32):
     if w.shape[1] != Cin:
         raise _lib.DpiError("conv: weight expects %d input channels, tensor has %d" % (w.shape[1], Cin))
     io = ((_lib.IO_X_BF16 | _lib.IO_DX_BF16) if _bf(x) else 0) | ((_lib.IO_Y_BF16 | _lib.IO_DY_BF16) if ydt == torch.bfloat16 else 0)
-    return ConvDesc(Cin, w.shape[0], D, H, W, k, kd, int(stride), PRECISION, io)
+    return ConvDesc(Cin, w.shape[0], D, H, W, k, kd, int(stride), precision(), io)
 
 
 def desc_out_dims(d):
@@ -274,6 +313,11 @@ _side_used = set()
 JOIN_AT = os.environ.get("DPI_JOIN_AT", "step")
 _side_keep = []
 _in_iteration = [False]
+# Gradients handed back to autograd BEFORE the stream that writes them has run (weight gradients on the side streams; with the branch stream also the
+# ResPath's BatchNorm gradients).  That is only sound if autograd's AccumulateGrad ADOPTS the tensor as .grad — which needs .grad to be None (zero_grad with
+# set_to_none=True), no hook, no second use of the parameter; anything else makes it clone or add on the main stream, ahead of the producer.
+# finish_backward(params) checks exactly that: every deferred tensor must BE some parameter's .grad storage afterwards.
+_deferred = []
 
 
 def begin_iteration():
@@ -281,6 +325,27 @@ def begin_iteration():
     the kernel-to-stream assignment is the same in every iteration and every run."""
     _side_rr[0] = 0
     _in_iteration[0] = True
+    del _deferred[:]
+
+
+def abort_iteration():
+    """An iteration raised between begin_iteration() and finish_backward(): join every stream and forget the per-iteration state, so that a later
+    bare loss.backward() joins per node again instead of believing it is still inside an Interpolator iteration."""
+    try:
+        if torch.cuda.is_available():
+            join_weight_grads(final=True)
+            join_branch()
+    finally:
+        _in_iteration[0] = False
+        _side_used.clear()
+        del _side_keep[:]
+        del _deferred[:]
+        _branch_open[0] = False
+
+
+def _defer(*tensors):
+    if JOIN_AT == "step" and _in_iteration[0]:
+        _deferred.extend(t.data_ptr() for t in tensors if t is not None)
 
 
 def _side_stream():
@@ -312,6 +377,7 @@ def conv_bwd_weight_async(d, x, chain, dy, dw):
         # (not dw: the parameter's .grad keeps it alive until the next zero_grad, and a second reference would make autograd's
         #  AccumulateGrad CLONE it on the main stream — before the side stream has written it — instead of adopting it)
         _side_keep.append((x, chain, dy))
+        _deferred.append(dw.data_ptr())
 
 
 def join_weight_grads(final=False):
@@ -326,12 +392,24 @@ def join_weight_grads(final=False):
     _side_keep.clear()
 
 
-def finish_backward():
+def finish_backward(params=None):
     """After loss.backward(), before the optimiser step: every weight gradient launched on a side stream (and everything the branch
-    stream still runs) is ordered in front of whatever the current stream does next."""
+    stream still runs) is ordered in front of whatever the current stream does next.
+    params (the optimised parameters): checks that every gradient that was handed to autograd ahead of its producer stream was ADOPTED as a
+    parameter's .grad — not cloned, not accumulated into an existing .grad (see _deferred) — and fails loudly otherwise."""
     join_weight_grads(final=True)
     join_branch()
     _in_iteration[0] = False
+    if _deferred and params is not None:
+        have = {p.grad.data_ptr() for p in params if p.grad is not None}
+        lost = [q for q in _deferred if q not in have]
+        if lost:
+            n = len(_deferred)
+            del _deferred[:]
+            raise _lib.DpiError("%d of %d gradients written on a side / branch stream were copied or accumulated by autograd before that stream ran "
+                                "(zero_grad(set_to_none=False), a gradient hook, retain_grad or a shared parameter?): with the once-per-step join "
+                                "(DPI_JOIN_AT=step) .grad must be None when backward starts; use DPI_JOIN_AT=node otherwise" % (len(lost), n))
+    del _deferred[:]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -350,7 +428,7 @@ def finish_backward():
 # Only inside an Interpolator iteration with the weight-gradient overlap on (patches >= 2^20 voxels, eager loop).
 # ------------------------------------------------------------------------------------------------
 BRANCH_STREAMS = os.environ.get("DPI_BRANCH", "1") == "1"
-BRANCH_SHORTCUT = os.environ.get("DPI_BRANCH_SHORT", "0") == "1"      # OFF: the first 3x3x3 layer of a block (64->4, 67->4, 25->8: few output channels) is itself at ~half the HBM bandwidth, the 1x1x1 layer beside it gains nothing (64->4 0.70 -> 1.05 ms with the 0.35 ms shortcut beside it; 31.1-31.5 ms per iteration with, 30.6-30.8 without)
+BRANCH_SHORTCUT = int(os.environ.get("DPI_BRANCH_SHORT", "0"))   # 2 (round 6): beside the SECOND and THIRD 3x3x3 layer of the block instead (4->8, 8->13: matrix-bound, they read 4 / 8 channels), started once the first one has drained; 1:     # OFF: the first 3x3x3 layer of a block (64->4, 67->4, 25->8: few output channels) is itself at ~half the HBM bandwidth, the 1x1x1 layer beside it gains nothing (64->4 0.70 -> 1.05 ms with the 0.35 ms shortcut beside it; 31.1-31.5 ms per iteration with, 30.6-30.8 without)
 BRANCH_SKIP = os.environ.get("DPI_BRANCH_SKIP", "1") == "1"
 BRANCH_SKIP_BWD = os.environ.get("DPI_BRANCH_SKIP_BWD", "1") == "1"
 _branch_streams = {}
@@ -701,6 +779,25 @@ class BatchNormFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None
 
 
+# Gradient fan-in of an encoder output (round 6).  The output x of the encoder block of a U-Net level has two consumers — the level's ResPath
+# (skip branch) and the stride-2 convolution that opens the deeper U (reference mulresunet.py:227-243) — so autograd used to ADD their two gradients
+# in a pass of its own (four aten `add` launches per iteration, 1.26 GB moved for the finest level).  With a FanIn handle shared by the two nodes
+# the stride-2 layer's backward-data ACCUMULATES into the ResPath's gradient instead (the kernels' `accumulate` flag: old + new in the epilogue,
+# the same fp32 sum the add pass formed) and returns no gradient of its own; the tap node in front of the ResPath then hands autograd the total.
+# Order (autograd runs ready nodes by descending creation order): SkipJoinFn.backward (last node of the level: first) publishes its dx, the deeper
+# U's backward follows, its last node — ConvBnActFn.backward of the stride-2 layer — accumulates, SkipTapFn.backward (created before the deeper U:
+# after it) returns the sum.  If the order ever differs (fan.dx not published yet), the node falls back to its own dx and autograd adds as before.
+FAN_IN = os.environ.get("DPI_FAN_IN", "1") == "1"
+
+
+class FanIn:
+    __slots__ = ("dx", "branched")
+
+    def __init__(self):
+        self.dx = None
+        self.branched = False
+
+
 class ConvBnActFn(torch.autograd.Function):
     """conv -> BatchNorm(train) -> LeakyReLU(slope) in three launches: the conv's epilogue emits the {sum, sum^2}
     partials, dpi_bn_finalize turns them into the per-channel chain, dpi_chain_apply writes the activation.
@@ -708,8 +805,9 @@ class ConvBnActFn(torch.autograd.Function):
     The conv bias feeds a BatchNorm, so its gradient is analytically zero and returned as zeros."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, stride, slope):
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, stride, slope, fan=None):
         x, w = _req(x, "conv input", act=True), _req(w, "conv weight")
+        ctx.fan = fan
         adt = act_dtype() if x.ndim == 5 else torch.float32
         if x.ndim != 5 and _bf(x):
             raise _lib.DpiError("conv_bn_act: bf16 storage is built for the 3-D nets only")
@@ -740,12 +838,19 @@ class ConvBnActFn(torch.autograd.Function):
             dw = torch.empty_like(w)
             conv_bwd_weight_async(d, x, None, dr, dw)
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            raw_conv_bwd_data(d, dr, w, dx)
+            fan = ctx.fan
+            if fan is not None and fan.dx is not None and fan.dx.shape == x.shape and fan.dx.dtype == x.dtype:
+                if fan.branched:
+                    join_branch("skip")          # the ResPath's backward-data wrote fan.dx on the branch stream
+                raw_conv_bwd_data(d, dr, w, fan.dx, accumulate=True)
+                fan.dx = None                    # consumed: x's whole gradient now reaches autograd through the tap node (FanIn above)
+            else:
+                dx = torch.empty_like(x)
+                raw_conv_bwd_data(d, dr, w, dx)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _zeros_like_or_none(ctx.bias_ref)
+            db = _zeros_like_or_none(ctx.bias_ref, dr)
         join_weight_grads()
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None
 
 
 def _cba_raw(d, x, in_chain, w, b, bn, slope, r_out, mi_out, chain_out):
@@ -759,12 +864,23 @@ def _cba_raw(d, x, in_chain, w, b, bn, slope, r_out, mi_out, chain_out):
                     bn.num_batches_tracked, mi_out, chain_out)
 
 
-def _zeros_like_or_none(b):
+# Bisect knob (tools/snr_protocol_gpu.py --dead-bias; never set by the product path): what the ~3.3 k conv biases that feed a
+# BatchNorm receive as "gradient".  "off" (default): None — they never move.  "sum": the per-channel sum of the pre-BatchNorm gradient, which is
+# what the reference's autograd hands Adam (main.py:200,213): analytically zero, numerically the rounding residue of that sum.  "noise": N(0, 1e-6^2)
+# — far above Adam's eps, so every dead bias takes full-size (~0.2 lr) random Adam steps: the upper bound of what the reference's residues can do.
+DEAD_BIAS = "off"
+
+
+def _zeros_like_or_none(b, dr=None):
     """Gradient of a conv bias that feeds a BatchNorm: identically zero — reported as None, which autograd and
     the optimisers treat as "no gradient" (torch.optim.Adam and FusedAdam skip such parameters; with zero moments the Adam
     update of a zero gradient is exactly 0, so the trajectory is the same).  Handing out cached zero tensors instead made
-    autograd clone each of them every iteration (48 device-to-device copies)."""
-    return None
+    autograd clone each of them every iteration (48 device-to-device copies).  (DEAD_BIAS above: the bisect variants.)"""
+    if b is None or DEAD_BIAS == "off":
+        return None
+    if DEAD_BIAS == "noise":
+        return torch.randn_like(b) * 1e-6
+    return dr.sum(dim=[0] + list(range(2, dr.ndim)), dtype=torch.float32)
 
 
 class Block3dFn(torch.autograd.Function):
@@ -800,11 +916,16 @@ class Block3dFn(torch.autograd.Function):
         S = torch.empty_like(R)
         chSA = torch.empty((2, Ct * 5), **f32)       # the two chains of the residual join, rows of one buffer (saved as a whole for the backward)
         chS, chA = chSA[0], chSA[1]
-        side_shortcut = branch_on() and BRANCH_SHORTCUT
-        if side_shortcut:       # the 1x1x1 shortcut (HBM-bound) beside the 3x3x3 chain (matrix-bound): it only needs the block input
+        side_shortcut = BRANCH_SHORTCUT if branch_on() else 0
+
+        def shortcut_on_branch():   # the 1x1x1 shortcut (HBM-bound) beside the 3x3x3 chain (matrix-bound): it only needs the block input
             with _Branch("short", x, S, miS, chS):
                 _cba_raw(dsc, x, None, ws, bs, bns_, slope, S, miS, chS)
+        if side_shortcut == 1:
+            shortcut_on_branch()
         _cba_raw(d1, x, None, w1, b1, bn1_, slope, r1, mi1, ch1)
+        if side_shortcut == 2:      # ordered behind the first layer (which reads the same 64-67 channels at half the HBM bandwidth already)
+            shortcut_on_branch()
         d2 = make_desc(r1, w2, 1, adt)
         _cba_raw(d2, r1, ch1, w2, b2, bn2_, slope, r2, mi2, ch2)
         d3 = make_desc(r2, w3, 1, adt)
@@ -883,8 +1004,8 @@ class Block3dFn(torch.autograd.Function):
             raw_conv_bwd_data_dual(d1, dR[:, s1], w1, dsc, dS, ws, dx)
         join_weight_grads()
         z = _zeros_like_or_none      # conv biases feed a BatchNorm: analytically zero gradient
-        return (dx, None, None, dw1, z(b1), dg1, de1, dw2, z(b2), dg2, de2, dw3, z(b3), dg3, de3, dws, z(bs), dgs, des,
-                dgA, deA, dgB, deB)
+        return (dx, None, None, dw1, z(b1, dR[:, s1]), dg1, de1, dw2, z(b2, dR[:, s2]), dg2, de2, dw3, z(b3, dR[:, s3]), dg3, de3,
+                dws, z(bs, dS), dgs, des, dgA, deA, dgB, deB)
 
 
 def _respath_bn_backward(dy, t, miB, gB, eB, slope, r3, mi3, g3, e3, r1, mi1, g1, e1, tless=False):
@@ -953,7 +1074,7 @@ class ResPath3dFn(torch.autograd.Function):
             raw_conv_bwd_data_dual(d3, dr3, w3, d1, dr1, w1, dx)
         join_weight_grads()
         z = _zeros_like_or_none
-        return dx, None, None, dw3, z(b3), dg3, de3, dw1, z(b1), dg1, de1, dgB, deB
+        return dx, None, None, dw3, z(b3, dr3), dg3, de3, dw1, z(b1, dr1), dg1, de1, dgB, deB
 
 
 def _skip_alloc(x, p, Cd):
@@ -1047,8 +1168,9 @@ class SkipJoinFn(torch.autograd.Function):
     already running on the branch stream (its input must then come through skip_tap())."""
 
     @staticmethod
-    def forward(ctx, x, deep, rp, slope, linear, pre, *p):
+    def forward(ctx, x, deep, rp, slope, linear, pre, fan, *p):
         x, deep = _req(x, "skip input", act=True), _req(deep, "deep input", act=True)
+        ctx.fan = fan
         L = _lib.load()
         Cd, Dd, Hd, Wd = _dims(deep)
         if pre is None:
@@ -1103,18 +1225,20 @@ class SkipJoinFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 raw_conv_bwd_data_dual(d3, dr3, w3, d1, dr1, w1, dx)
-            return dx, dw3, dg3, de3, dw1, dg1, de1, dgB, deB
+            return dx, dw3, dg3, de3, dw1, dg1, de1, dgB, deB, _zeros_like_or_none(b3, dr3), _zeros_like_or_none(b1, dr1)
 
         if ctx.branched and branch_on() and BRANCH_SKIP_BWD:
             # the deeper U's backward (critical path, main stream) does not wait for this: SkipTapFn.backward joins, just before the
             # encoder block of the level consumes dx.  Tensors allocated in here come from the branch stream's pool.
             with _Branch("skip", dcat, x, r3, r1, t, mi3, mi1, miB):
-                dx, dw3, dg3, de3, dw1, dg1, de1, dgB, deB = respath_backward()
+                dx, dw3, dg3, de3, dw1, dg1, de1, dgB, deB, db3, db1 = respath_backward()
+            _defer(dg3, de3, dg1, de1, dgB, deB, db3, db1)
         else:
-            dx, dw3, dg3, de3, dw1, dg1, de1, dgB, deB = respath_backward()
+            dx, dw3, dg3, de3, dw1, dg1, de1, dgB, deB, db3, db1 = respath_backward()
         join_weight_grads()
-        z = _zeros_like_or_none
-        return dx, ddeep, None, None, None, None, dw3, z(b3), dg3, de3, dw1, z(b1), dg1, de1, dgB, deB
+        if ctx.fan is not None and dx is not None:
+            ctx.fan.dx, ctx.fan.branched = dx, bool(ctx.branched and branch_on() and BRANCH_SKIP_BWD)
+        return dx, ddeep, None, None, None, None, None, dw3, db3, dg3, de3, dw1, db1, dg1, de1, dgB, deB
 
 
 class LeakyReLUFn(torch.autograd.Function):
@@ -1370,8 +1494,8 @@ def batch_norm(x, gamma, beta, running_mean=None, running_var=None, nbt=None, sl
     return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, nbt, float(slope), float(pre_slope))
 
 
-def conv_bn_act(x, w, b, gamma, beta, running_mean, running_var, nbt, stride=1, slope=0.2):
-    return ConvBnActFn.apply(x, w, b, gamma, beta, running_mean, running_var, nbt, int(stride), float(slope))
+def conv_bn_act(x, w, b, gamma, beta, running_mean, running_var, nbt, stride=1, slope=0.2, fan=None):
+    return ConvBnActFn.apply(x, w, b, gamma, beta, running_mean, running_var, nbt, int(stride), float(slope), fan)
 
 
 def _cba_params(m):
@@ -1391,10 +1515,11 @@ def respath3d(x, rp, slope):
     return ResPath3dFn.apply(x, rp, slope, *p)
 
 
-def skip_join(x, deep, rp, slope, mode, pre=None):
-    """cat[ResPath3d(x), Upsample(deep)] written in place (zero-copy concat).  pre: handle of skip_begin(x, ...) (x through skip_tap)."""
+def skip_join(x, deep, rp, slope, mode, pre=None, fan=None):
+    """cat[ResPath3d(x), Upsample(deep)] written in place (zero-copy concat).  pre: handle of skip_begin(x, ...) (x through skip_tap).
+    fan: the FanIn handle this node shares with the stride-2 layer of the deeper U (x through skip_tap as well)."""
     p = _cba_params(rp.conv3x3) + _cba_params(rp.conv1x1) + [rp.bn.weight, rp.bn.bias]
-    return SkipJoinFn.apply(x, deep, rp, slope, mode != "nearest", pre, *p)
+    return SkipJoinFn.apply(x, deep, rp, slope, mode != "nearest", pre, fan, *p)
 
 
 def leaky_relu(x, slope=0.2):

@@ -41,6 +41,14 @@ class FusedAdam(torch.optim.Optimizer):
         self._capture_ready = None
         self._table_copied = None       # event recorded after the last async H2D copy out of _table_host
 
+    def zero_grad(self, set_to_none=True):
+        """Gradients are always dropped, never zeroed in place: the fused nodes hand autograd freshly written tensors which AccumulateGrad adopts
+        as .grad (no copy, no add pass); with the once-per-step join (ops.JOIN_AT) a surviving .grad would be accumulated into on the main stream
+        before the side stream has produced the new gradient."""
+        if not set_to_none:
+            raise _lib.DpiError("FusedAdam.zero_grad(set_to_none=False) is not supported: gradients are adopted, not accumulated (ops.finish_backward)")
+        super().zero_grad(set_to_none=True)
+
     def prepare_capture(self):
         """Allocate the pinned staging buffer + device table the next captured step() will use (see _refresh_table)."""
         n = len(self._params) * 5

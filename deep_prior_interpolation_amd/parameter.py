@@ -53,6 +53,10 @@ _FLAGS = [
     (("--noise_dist",), dict(type=str, default="n", required=False, choices=["n", "u", "c"],
                              help="Type of noise for the input tensor [(n)ormal, (u)niform, (c)auchy]")),
     (("--noise_std",), dict(type=float, default=0.1, required=False, help="Standard deviation of the noise for the input tensor")),
+    (("--noise_source",), dict(type=str, default="philox", required=False, choices=["philox", "torch_cpu"],
+                             help="ours: philox = z and the per-iteration perturbation drawn on the GPU (counter-based, the default); torch_cpu = parity "
+                                  "mode: both drawn by torch's CPU generator in the reference's order (main.py:59-64,143-150, including the "
+                                  "--param_noise draws that only shift the stream) and uploaded: same seed, same input stream as the reference")),
     (("--data_forgetting_factor",), dict(type=int, default=0, required=False,
                                          help="Duration of additional decimated data to the input noise tensor")),
     (("--filter_noise_with_wavelet",), dict(action="store_true", default=False,

@@ -43,7 +43,7 @@ extern "C" {
 #define DPI_CHAIN_STRIDE 5
 
 const char* dpi_last_error(void);
-/* ABI version: 300 = round 3 (dpi_conv_desc carries its own size as first field), 301 adds dpi_conv_fwd_ws / dpi_conv_bwd_data_ws /
+/* ABI version (404 = round 6: the ten dpi_set_* tuning functions left the ABI for dpi_set_option): 300 = round 3 (dpi_conv_desc carries its own size as first field), 301 adds dpi_conv_fwd_ws / dpi_conv_bwd_data_ws /
  * dpi_conv_bwd_data_dual, 401 = dpi_pack_scratch_bytes / dpi_pack_release, 402 = dpi_pack_forget (round 5), 403 = dpi_join_bwd (round 5), 400 = round 4: dpi_conv_desc grows the `io` field (bf16 storage of activations) and the elementwise entry
  * points get `_io` twins that take the storage types of their tensors.  A binding checks `>=` the version it was written against and
  * dpi_conv_desc_size() == its own struct size. */
@@ -54,12 +54,28 @@ int dpi_device_info(int device, int* cus, int* lds_bytes, size_t* hbm_bytes, cha
  * rocprofv3's kernel trace records launch grids but not kernel arguments, so tools/rocpd_stats.py uses these markers to
  * attribute the dispatches that follow (in host launch order) to the layer the caller tagged; id = 1 ends a scope. */
 int dpi_profile_marker(int id, void* stream);
-/* Tuning knobs of the backward-weight MFMA launch plan (experiments / tools only): workgroups aimed at (<= 0 keeps the
- * current value) and the XCD-aware workgroup order (0 / 1; < 0 keeps it). */
-void dpi_set_bw_tuning(int want_workgroups, int xcd_order);
-/* bf16 convolution kernel, tests / tools only: bits 0-2 skip phases (timing experiments, wrong results), bit 3 routes EVERY
- * 3x3(x3) stride-1 convolution of a precision = 1 descriptor through it (default: only the shapes where it beats the fp32 kernels). */
-void dpi_set_bf16_debug(int flags);
+/* ABI 404.  The ONE process-global switchboard of the library, for tests, tools and A/B experiments only — the product path (ops.py, main.py,
+ * parallel.py, bench.py's timed region) never calls it: what a launch computes is a function of its descriptor and arguments alone (SURVEY §8(b):
+ * "no hidden global state").  Every key selects between launch PLANS or kernel VARIANTS that compute the same result (or, for the *_debug keys,
+ * skips phases for timing experiments and says so); none changes the arithmetic contract of an entry point.  Returns DPI_OK, or DPI_E_ARG for
+ * an unknown key / a value out of range.  Keys (defaults in brackets; the environment variable that sets the initial value, if any):
+ *   "splitk"                   [1]  0: no input-channel split of coarse-level launches (DPI_SPLITK)
+ *   "dual_bwd_data"            [1]  0: dpi_conv_bwd_data_dual always runs two launches (DPI_NO_DUAL)
+ *   "bw_pair"                  [2]  backward-weight, two 4-channel groups per workgroup: 0 off, 1 every layer with >= 2 full groups, 2 the long
+ *                                   group loops of the finest level only (DPI_BW_PAIR)
+ *   "bw_workgroups"            [-]  workgroups the backward-weight MFMA launch plan aims at (> 0)
+ *   "bw_xcd_order"             [1]  XCD-aware workgroup order of that plan (0 / 1)
+ *   "mfma_min_cout"            [8]  3x3(x3) stride-1 forward / backward-data with at least this many output channels run the fp32-MFMA stencil
+ *   "bwd_weight_mfma_min_cout" [8]  ... the same threshold of the backward-weight dispatch
+ *   "fewco_mfma"               [1]  0: forward 3x3x3 with Cout <= 4 back on the VALU kernel
+ *   "q4"                       [1]  4x4x1-MFMA kernel for <= 8 output channels: 0 off, 1 where it pays, 2 wherever it can run (tests)
+ *   "q4_ck"                    [0]  its chunk variant: 2 planar, 4 channel-interleaved, 0 by shape
+ *   "q4_debug"                 [0]  its phase-skipping bits (timing experiments, WRONG results): 0 no input loads after the first chunk, 1 no LDS
+ *                                   stores after it, 2 no MFMAs, 3 no output stores, 5 no barriers; bits 8-15 = KiB of extra dynamic LDS
+ *   "bf16_debug"               [0]  bf16 stencil kernel: bits 0-2 skip phases (WRONG results), bit 3 routes EVERY 3x3(x3) stride-1 convolution of
+ *                                   a precision = 1 descriptor through it (default: only the shapes where it beats the fp32 kernels)
+ * (the per-knob functions behind the keys live in csrc/dpi_hip_internal.h and are not exported). */
+int dpi_set_option(const char* key, int value);
 
 /* ---------------------------------------------------------------- convolution ------------------
  * Replaces nn.Conv3d / nn.Conv2d built at architectures/base.py:123,176 (k in {1,3}, stride in {1,2},
@@ -116,8 +132,6 @@ int dpi_conv_fwd_ws(const dpi_conv_desc* d, const float* x, const float* x_chain
                     const float* bias, float* y, double* stat_partials, float* ws, size_t ws_floats, void* stream);
 int dpi_conv_bwd_data_ws(const dpi_conv_desc* d, const float* dy, const float* w, float* dx,
                          int accumulate, float* ws, size_t ws_floats, void* stream);
-/* 0 switches the input-channel split off (A/B testing; default on, DPI_SPLITK=0 in the environment does the same) */
-void dpi_set_splitk(int on);
 /* dx (+)= conv_transpose(dy3, w3) + conv_transpose(dy1, w1) for a 3x3(x3) stride-1 layer d3 and a 1x1(x1) layer d1 that read the SAME
  * tensor (equal Cin, D, H, W): Block3d.conv1 + shortcut (mulresunet.py:72-96) and ResPath3d.conv3x3 + conv1x1 (mulresunet.py:99-113),
  * whose input gradient is the sum of the two transposed convolutions.  Where the fp32-MFMA stencil kernel serves d3, the 1x1x1 term is
@@ -126,32 +140,12 @@ void dpi_set_splitk(int on);
 int dpi_conv_bwd_data_dual(const dpi_conv_desc* d3, const float* dy3, const float* w3,
                            const dpi_conv_desc* d1, const float* dy1, const float* w1,
                            float* dx, int accumulate, float* ws, size_t ws_floats, void* stream);
-/* 0: dpi_conv_bwd_data_dual always runs two launches (A/B testing; DPI_NO_DUAL in the environment does the same) */
-void dpi_set_dual_bwd_data(int on);
-/* backward-weight, two 4-channel groups per workgroup: 0 off, 1 every layer with >= 2 full groups, 2 (default) the long group loops of
- * the finest level only (DPI_BW_PAIR in the environment sets the initial value; tests force 1 to cover the kernel on small shapes) */
-void dpi_set_bw_pair(int mode);
 /* dw[Cout][Cin][kd][k][k] = sum_p dy[co][p] * T(x)[ci][p*stride + tap - pad].
  * workspace: float[dpi_conv_bwd_weight_ws_floats(d)].  */
 size_t dpi_conv_bwd_weight_ws_floats(const dpi_conv_desc* d);
 int dpi_conv_bwd_weight(const dpi_conv_desc* d, const float* x, const float* x_chain, const float* dy,
                         float* dw, float* ws, size_t ws_floats, void* stream);
 
-/* Dispatch thresholds (A/B testing): k=3 stride-1 convolutions with at least this many output channels run the
- * fp32-MFMA stencil kernels (conv_mfma.hip), fewer use the VALU kernels.  Default 8. */
-void dpi_set_mfma_min_cout(int n);
-void dpi_set_bwd_weight_mfma_min_cout(int n);
-/* Tuning / test hook: 0 routes forward 3x3x3 convs with Cout <= 4 back to the VALU kernel instead of the (co, kw)-row
- * MFMA kernel (csrc/conv_fewco_mfma.hip). */
-void dpi_set_fewco_mfma(int on);
-/* Tuning / test hook of the 4x4x1-MFMA kernel for 3x3x3 stride-1 convolutions with <= 8 output channels (csrc/conv_q4_mfma.hip):
- * on = 0 routes those shapes back to the 16x16x4 kernels, 1 (default) uses it where it pays, 2 wherever it can run (tests); < 0 keeps
- * the setting; ck = 2 / 4 forces the planar (2 input channels per chunk, ds_read_b32 operands) / the channel-interleaved variant
- * (4 channels per chunk, ds_read_b128 operands), 0 picks by shape (default); other values keep the setting. */
-void dpi_set_q4(int on, int ck);
-/* ... its phase-skipping switches (timing experiments, wrong results): bit 0 no input loads after the first chunk, bit 1 no LDS stores
- * after it, bit 2 no MFMAs, bit 3 no output stores, bit 5 no barriers; bits 8-15 = KiB of extra dynamic LDS (occupancy experiments). */
-void dpi_set_q4_debug(int flags);
 
 /* ---------------------------------------------------------------- BatchNorm / activations -------
  * Replaces nn.BatchNorm3d/2d in training mode (base.py:164,214; mulresunet.py:80-81,104,225) and

@@ -253,3 +253,49 @@ def test_conv_at_field_scale_patch(ops, cin, cout, k):
         got = dx[:, :, box[0][0]:box[0][1], box[1][0]:box[1][1], box[2][0]:box[2][1]]
         worst = max(worst, rel(got, ref))
     assert worst < 5e-6, worst
+
+
+# ---------------------------------------------------------------- the whole net at the bench geometry against the REFERENCE ----------
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_whole_net_first_iterations_at_bench_geometry_against_the_reference_recording(seed):
+    """The assembled default MulResUnet3D (5 923 614 parameters) on the 256x128x128 patch — the geometry the metric is quoted on — against the
+    REFERENCE's own recording of iterations 0..2 there (tests/golden/snr_bench_head_256x128x128.npz, oracle/make_snr_spread.py --mid 256 128 128:
+    the reference's Interpolator on CPU; loss[0] = 1.3799078 / 1.3789475 / 1.3842244 for seeds 0 / 1 / 2).
+    --noise_source torch_cpu reproduces the reference's stream (u.set_seed(s) -> build_model -> z = 0.1 * N(0,1) -> 0.03 * z.clone().normal_() per
+    iteration from torch's CPU generator, order of reference main.py:59-64,148-150; the CPU half of that is pinned without a GPU by
+    tests/test_host.py::test_torch_cpu_noise_source_reproduces_the_reference_stream), so iteration 0 is THE SAME function of THE SAME numbers on both
+    sides: every convolution, BatchNorm over 4.2 M voxels, join, trilinear up-sampling and the masked loss at full size in one number.
+    Bars: iteration 0 — loss 1e-5 relative, SNR 1e-3 dB, PCORR 1e-4 (forward only); iteration 1 — loss 2e-3 relative (one Adam step on the HIP
+    gradients: the reference itself moves by 7e-4 between 2 and 3 CPU threads there); iteration 2 — 5e-2 (two steps of ~lr per
+    weight with weights of that size: the trajectory is already decorrelating, App. D)."""
+    import hashlib
+    import os
+    from deep_prior_interpolation_amd import utils as u
+    from deep_prior_interpolation_amd.main import Interpolator
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "snr_bench_head_256x128x128.npz"))
+    assert tuple(int(n) for n in z["shape"]) == FULL
+    if str(z["torch"]) != torch.__version__:
+        pytest.skip("the CPU generator's stream is pinned to torch %s (the build that recorded the fixture)" % z["torch"])
+    k = [int(s) for s in z["seed"]].index(seed)
+    vol = u.hyperbolic_volume(FULL, seed=0)
+    mask = u.random_trace_mask(FULL, 0.66, seed=1)
+    assert hashlib.sha1(vol.astype(np.float32).tobytes()).hexdigest() == str(z["volume_sha1"])
+    assert hashlib.sha1(mask.astype(np.uint8).tobytes()).hexdigest() == str(z["mask_sha1"])
+    args = parse_arguments(str(z["argv"]).split() + ["--epochs", "3", "--gpu", "0", "--noise_source", "torch_cpu"])
+    args.param_noise = False                                   # as the recording (make_snr_spread.run_seed)
+    u.set_seed(seed)
+    T = Interpolator(args, "/tmp", seed=seed)
+    std = T.load_data({"image": (vol.astype(np.float64) * args.gain)[..., None], "mask": mask.astype(np.float64)[..., None], "name": "0"})
+    assert abs(std - float(z["std"][k])) < 1e-4
+    T.build_model()
+    T.build_input()
+    T.optimize(verbose=False)
+    loss, snr, pc = (np.array(h, dtype=np.float64) for h in (T.history.loss, T.history.snr, T.history.pcorr))
+    rl, rs, rp = (z[n][k, :3].astype(np.float64) for n in ("loss", "snr", "pcorr"))
+    print("seed %d: loss HIP %s reference %s (relative %s); SNR %s / %s dB; PCORR %s / %s"
+          % (seed, loss, rl, np.abs(loss - rl) / rl, snr, rs, pc, rp))
+    assert abs(loss[0] - rl[0]) <= 1e-5 * rl[0]
+    assert abs(snr[0] - rs[0]) < 1e-3 and abs(pc[0] - rp[0]) < 1e-4
+    assert abs(loss[1] - rl[1]) <= 2e-3 * rl[1]
+    assert abs(loss[2] - rl[2]) <= 5e-2 * rl[2]

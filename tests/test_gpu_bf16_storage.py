@@ -335,12 +335,12 @@ def test_dual_backward_fused_into_the_bf16_kernel(ops, cin, c3, c1, shape, acc, 
         assert rel(dx, ref) < 2e-6, rel(dx, ref)
     # the library really took one launch: with the fusion switched off the same call must give the two-launch result (two roundings in bf16)
     L = ops._lib.load()
-    L.dpi_set_dual_bwd_data(0)
+    L.set_option("dual_bwd_data", 0)
     try:
         dx2 = base.to(DEV).to(adt) if acc else torch.empty_like(xproto)
         ops.raw_conv_bwd_data_dual(d3, dy3.to(DEV).to(adt), w3.to(DEV), d1, dy1.to(DEV).to(adt), w1.to(DEV), dx2, accumulate=acc)
     finally:
-        L.dpi_set_dual_bwd_data(1)
+        L.set_option("dual_bwd_data", 1)
     assert rel(dx2.float(), ref) < (6e-3 if store == "bf16" else 2e-6)
 
 
@@ -589,7 +589,7 @@ def test_a_long_multi_patch_job_recycles_the_packed_weight_scratch(ops):
                             "--upsample", "linear", "--loss", "mae", "--epochs", "2", "--gpu", "0", "--precision", "bf16"])
     vol = (u.hyperbolic_volume(shape, seed=2).astype(np.float64) * 40)[..., None]
     mask = u.random_trace_mask(shape, 0.5, seed=3).astype(np.float64)[..., None]
-    L.dpi_set_bf16_debug(8)
+    L.set_option("bf16_debug", 8)
     try:
         T = Interpolator(args, "/tmp")
         per_net, last = None, None
@@ -619,7 +619,7 @@ def test_a_long_multi_patch_job_recycles_the_packed_weight_scratch(ops):
         np.testing.assert_array_equal(last[0], np.array(T2.history.loss))
         np.testing.assert_array_equal(last[1], T2.out_best)
     finally:
-        L.dpi_set_bf16_debug(0)
+        L.set_option("bf16_debug", 0)
         ops.set_precision("fp32")
         ops.set_storage("fp32")
 
@@ -641,20 +641,23 @@ def test_one_iteration_in_storage_mode_against_fp32_storage(ops, shape):
     out = {}
 
     def run(name, T, hook):
-        T.apply_precision()
         hooks = [m.register_forward_hook(hook) for m in T.net.modules() if type(m).__name__ == "MultiResBlock"]
         T.net.zero_grad()
-        o = T.net(z.to(BF) if ops.STORAGE_BF16 else z)
-        loss, _ = ops.masked_loss(o, T.img_, T.mask_, "mae")
+        with T.precision_scope():                                          # this Interpolator's mode, on this thread, for the nodes built inside
+            stored.append(ops.storage_bf16())
+            o = T.net(z.to(BF) if ops.storage_bf16() else z)
+            loss, _ = ops.masked_loss(o, T.img_, T.mask_, "mae")
+        assert not ops.storage_bf16()                                      # ... and nothing of it outlives the scope
         loss.backward()
         for h in hooks:
             h.remove()
         out[name] = (o.detach().clone(), float(loss), {k: p.grad.detach().clone() for k, p in T.net.named_parameters() if p.grad is not None and p.ndim == 5})
+    stored = []
     run("fp32", T32, lambda mod, i, o: seen.append(("fp32", o.dtype)))
-    assert not ops.STORAGE_BF16
+    assert stored == [False]
     run("hand", T32, lambda mod, i, o: o.to(BF).float())                    # calibration: block outputs rounded, everything else fp32
     run("bf16", T16, lambda mod, i, o: seen.append(("bf16", o.dtype)))
-    assert ops.STORAGE_BF16
+    assert stored == [False, False, True]
     assert {d for n, d in seen if n == "bf16"} == {BF} and {d for n, d in seen if n == "fp32"} == {torch.float32}
     o32, l32, g32 = out["fp32"]
     oh, lh, gh = out["hand"]
@@ -701,7 +704,9 @@ def test_nets_without_fused_3d_nodes_keep_fp32_storage(ops):
     T = _net_run((16, 16, 16), "bf16", 2, extra=["--activation", "ELU"])
     assert not T.storage_bf16_ok()
     T.optimize(verbose=False)
-    assert not ops.STORAGE_BF16 and np.isfinite(T.history.loss).all()
+    with T.precision_scope():
+        assert not ops.storage_bf16() and ops.precision() == 1
+    assert np.isfinite(T.history.loss).all()
     args = parse_arguments(["--imgdir", "x", "--datadim", "2d", "--filters", "4", "8", "--skip", "4", "--inputdepth", "4", "--epochs", "2", "--gpu", "0",
                             "--precision", "bf16"])
     u.set_seed(0)

@@ -331,3 +331,85 @@ def test_precision_modes_through_the_loop_at_awkward_shapes(shape):
     assert abs(losses["split"][0] - ref[0]) <= 2e-5 * ref[0]
     for prec in ("bf16", "bf16mm", "split"):
         assert abs(losses[prec][-1] - ref[-1]) <= 0.1 * ref[-1], prec
+
+
+# ---------------------------------------------------------------- round 6: stream-schedule invariants, parity noise source -------------
+def _tiny_default_interpolator(shape=(16, 16, 16), extra=(), epochs=3):
+    from deep_prior_interpolation_amd import utils as u
+    from deep_prior_interpolation_amd.main import Interpolator
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    a = parse_arguments(["--imgdir", "x", "--datadim", "3d", "--upsample", "linear", "--gain", "40", "--epochs", str(epochs), "--gpu", "0"] + list(extra))
+    vol = u.hyperbolic_volume(shape, seed=0)
+    mask = u.random_trace_mask(shape, 0.5, seed=1)
+    u.set_seed(0)
+    T = Interpolator(a, "/tmp")
+    T.load_data({"image": (vol.astype(np.float64) * a.gain)[..., None], "mask": mask.astype(np.float64)[..., None], "name": "0"})
+    T.build_model()
+    T.build_input()
+    return T, a
+
+
+def test_deferred_gradients_must_be_adopted_by_autograd():
+    """with the once-per-step join the fused nodes hand autograd weight gradients the side stream has not written yet; that is
+    sound only if AccumulateGrad adopts the tensor (.grad None at the start of backward).  A surviving .grad (zero_grad(set_to_none=False), a
+    loop that keeps gradients) makes autograd ADD on the main stream, ahead of the producer: it must be refused loudly, the streams joined and the
+    per-iteration state reset — and the next clean iteration must work."""
+    from deep_prior_interpolation_amd import _lib, ops
+    from deep_prior_interpolation_amd.optim import FusedAdam
+    T, a = _tiny_default_interpolator()
+    T.optimizer = FusedAdam(T.net.parameters(), lr=a.lr)
+    with pytest.raises(_lib.DpiError):
+        T.optimizer.zero_grad(set_to_none=False)
+    ops.set_weight_grad_overlap(True)
+    try:
+        T.optimizer.zero_grad()
+        T.optimization_loop()                                   # clean iteration: every deferred gradient is a parameter's .grad
+        assert not ops._in_iteration[0] and not ops._deferred
+        w = next(p for p in T.net.parameters() if p.ndim == 5)
+        g_clean = w.grad.clone()
+        for p in T.net.parameters():                             # what zero_grad(set_to_none=False) leaves behind
+            if p.grad is not None:
+                p.grad = torch.zeros_like(p.grad)
+        with pytest.raises(_lib.DpiError, match="side / branch stream"):
+            T.optimization_loop()
+        assert not ops._in_iteration[0] and not ops._deferred and not ops._side_keep
+        T.optimizer.zero_grad()
+        T.optimization_loop()
+        assert torch.isfinite(w.grad).all() and w.grad.shape == g_clean.shape
+    finally:
+        ops.set_weight_grad_overlap(False)
+        ops.abort_iteration()
+
+
+def test_an_iteration_that_raises_leaves_no_iteration_state_behind(monkeypatch):
+    from deep_prior_interpolation_amd import ops
+    from deep_prior_interpolation_amd.optim import FusedAdam
+    T, a = _tiny_default_interpolator()
+    T.optimizer = FusedAdam(T.net.parameters(), lr=a.lr)
+    ops.set_weight_grad_overlap(True)
+    try:
+        def boom(*_a, **_k):
+            raise RuntimeError("boom")
+        monkeypatch.setattr(ops, "masked_loss", boom)
+        with pytest.raises(RuntimeError, match="boom"):
+            T.optimization_loop()
+        assert not ops._in_iteration[0] and not ops._side_keep and not ops._deferred and not ops._branch_open[0]
+    finally:
+        ops.set_weight_grad_overlap(False)
+
+
+def test_torch_cpu_noise_source_runs_eagerly_and_is_reproducible():
+    """--noise_source torch_cpu: z and the perturbation come from torch's CPU generator — the loop cannot be a graph (auto picks eager, explicit
+    graph mode is refused) and two runs from the same seed give the same trajectory; the Philox default gives another."""
+    runs = []
+    for src in ("torch_cpu", "torch_cpu", "philox"):
+        T, a = _tiny_default_interpolator(extra=["--noise_source", src], epochs=4)
+        assert T.graph_capable() == (src == "philox")
+        if src == "torch_cpu":
+            with pytest.raises(ValueError):
+                T.optimize(verbose=False, mode="graph")
+            assert T._z_cpu is not None and torch.equal(T._z_cpu, T.input_.cpu())
+        T.optimize(verbose=False)
+        runs.append(np.array(T.history.loss))
+    assert len(runs[0]) == 4 and np.array_equal(runs[0], runs[1])
+    assert not np.allclose(runs[0][1:], runs[2][1:], rtol=1e-6)

@@ -360,12 +360,15 @@ def test_fused_block_nodes_match_leaf_by_leaf_execution(shape, upsample, overlap
             assert rel(b1[k], b2[k].cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("shortcut,precision", [(False, "fp32"), (True, "fp32"), (False, "bf16")])
+@pytest.mark.parametrize("shortcut,precision", [(0, "fp32"), (1, "fp32"), (2, "fp32"), (0, "bf16"), (2, "bf16")])
 def test_branch_stream_schedule_is_bit_identical_to_the_serial_one(monkeypatch, shortcut, precision):
     """Round 5: weight gradients joined once per step (ops.JOIN_AT = "step"), the ResPath half of every level join — forward and
     backward — on the branch stream (ops.skip_begin / SkipTapFn), optionally the 1x1x1 shortcuts too.  Same kernels on the same
     operands in the same per-tensor order: losses, SNR, best output and every weight after 4 Adam iterations must equal the serial
-    schedule (per-node joins, no branch stream) BIT FOR BIT — a missing stream dependency shows up as a difference (or NaN)."""
+    schedule (per-node joins, no branch stream) BIT FOR BIT — a missing stream dependency shows up as a difference (or NaN).
+    Round 6: shortcut = 2 starts the 1x1x1 shortcut behind the block's first 3x3x3 layer (beside the second and third); and the gradient fan-in
+    of every encoder output happens inside the stride-2 layer's backward-data (ops.FanIn: old + new in the kernel's epilogue instead of an aten
+    add pass) — the same fp32 sum, so the reference run (no fan-in, autograd adds) must still be reproduced bit for bit, with and without streams."""
     from deep_prior_interpolation_amd import ops, utils as u
     from deep_prior_interpolation_amd.main import Interpolator
     from deep_prior_interpolation_amd.parameter import parse_arguments
@@ -375,9 +378,10 @@ def test_branch_stream_schedule_is_bit_identical_to_the_serial_one(monkeypatch, 
     vol = u.hyperbolic_volume(shape, seed=4)[..., None] * 40.0
     mask = u.random_trace_mask(shape, 0.6, seed=5)[..., None].astype(np.float64)
 
-    def run(join_at, branch):
+    def run(join_at, branch, fan_in):
         monkeypatch.setattr(ops, "JOIN_AT", join_at)
         monkeypatch.setattr(ops, "BRANCH_STREAMS", branch)
+        monkeypatch.setattr(ops, "FAN_IN", fan_in)
         monkeypatch.setattr(ops, "BRANCH_SHORTCUT", shortcut)
         u.set_seed(0)
         T = Interpolator(args, "/tmp")
@@ -391,9 +395,9 @@ def test_branch_stream_schedule_is_bit_identical_to_the_serial_one(monkeypatch, 
         return (np.array(T.history.loss), np.array(T.history.snr), T.out_best.copy(),
                 {k: v.detach().cpu().numpy().copy() for k, v in T.net.state_dict().items()})
     try:
-        l0, s0, o0, w0 = run("node", False)
-        for _ in range(3):          # a race need not show up in every run
-            l1, s1, o1, w1 = run("step", True)
+        l0, s0, o0, w0 = run("node", False, False)
+        for k in range(4):          # a race need not show up in every run; the last run: the serial schedule with the fused fan-in
+            l1, s1, o1, w1 = run("step", True, True) if k < 3 else run("node", False, True)
             assert ops.OVERLAP_WEIGHT_GRADS and not ops._in_iteration[0] and not ops._side_keep
             np.testing.assert_array_equal(l0, l1)
             np.testing.assert_array_equal(s0, s1)

@@ -159,7 +159,7 @@ def test_conv_input_channel_split_vs_oracle(ops, cin, cout, shape, stride):
     """Coarse-level launches (few output tiles, many input channels) split the input-channel loop over blockIdx.z into a workspace
     and sum the partial outputs in a fixed order (dpi_conv_fwd_ws / dpi_conv_bwd_data_ws): forward with chain, bias and the
     statistics epilogue, backward-data with fan-in, against the fp64 oracle; the unsplit launch of the same problem
-    (dpi_set_splitk(0), and the entry points without a workspace) agrees to rounding; two runs are bit-identical."""
+    (dpi_set_option("splitk", 0), and the entry points without a workspace) agrees to rounding; two runs are bit-identical."""
     import ctypes as C
     from deep_prior_interpolation_amd import _lib
     L = _lib.load()
@@ -207,7 +207,7 @@ def test_conv_input_channel_split_vs_oracle(ops, cin, cout, shape, stride):
         ops.raw_conv_bwd_data(d, dyg, wg, dx2, accumulate=True)
         assert rel(dx2, dxr + base.double()) < 2e-6
     # the same launches without the split
-    L.dpi_set_splitk(0)
+    L.set_option("splitk", 0)
     try:
         assert L.dpi_conv_fwd_ws_floats(C.byref(d)) == 0
         y0, part0 = fwd()
@@ -216,7 +216,7 @@ def test_conv_input_channel_split_vs_oracle(ops, cin, cout, shape, stride):
             ops.raw_conv_bwd_data(d, dyg, wg, dx0)
             assert rel(dx0, dxr) < 2e-6
     finally:
-        L.dpi_set_splitk(1)
+        L.set_option("splitk", 1)
     assert rel(y0, yr) < 2e-6 and rel(y, y0) < 2e-6
     np.testing.assert_allclose(part0.view(nblk, cout, 2).sum(0).cpu().numpy(), p.numpy(), rtol=1e-6, atol=1e-3)
     # an ABI-300 caller (no workspace) gets the unsplit launch
@@ -265,11 +265,11 @@ def test_conv_bwd_data_dual_vs_oracle(ops, cin, c3, c1, shape):
     ops.raw_conv_bwd_data_dual(d3, dy3g, w3g, d1, dy1g, w1g, dxa, accumulate=True)
     assert rel(dxa, ref + base.double()) < 2e-6
     dx2 = torch.full(xg.shape, float("nan"), device=DEV)
-    L.dpi_set_dual_bwd_data(0)
+    L.set_option("dual_bwd_data", 0)
     try:
         ops.raw_conv_bwd_data_dual(d3, dy3g, w3g, d1, dy1g, w1g, dx2)
     finally:
-        L.dpi_set_dual_bwd_data(1)
+        L.set_option("dual_bwd_data", 1)
     assert rel(dx2, ref) < 2e-6 and rel(dx, dx2) < 2e-6
     dx3 = torch.empty_like(dx)
     ops.raw_conv_bwd_data(d1, dy1g, w1g, dx3)
@@ -297,14 +297,14 @@ def test_conv_bwd_weight_pair_kernel_vs_oracle(ops, cin, cout, shape):
     d = ops.make_desc(xg, w.to(DEV), 1)
     res = {}
     for mode in (1, 0):
-        L.dpi_set_bw_pair(mode)
+        L.set_option("bw_pair", mode)
         try:
             for use_chain in (False, True):
                 dw = torch.full(w.shape, float("nan"), device=DEV)
                 ops.raw_conv_bwd_weight(d, xg, cg if use_chain else None, dyg, dw)
                 res[(mode, use_chain)] = dw
         finally:
-            L.dpi_set_bw_pair(2)
+            L.set_option("bw_pair", 2)
     for use_chain in (False, True):
         wr = w.double().requires_grad_(True)
         O.conv_nd((tx if use_chain else x).double(), wr, None, 1).backward(dy.double())
@@ -730,7 +730,7 @@ def test_conv_bf16_mode_vs_oracle(ops, cin, cout, shape, k, monkeypatch):
         the bf16 rounding envelope of the exact result (5e-3 norm-wise).  Backward-data runs the same kernel (flipped weights)."""
     monkeypatch.setattr(ops, "PRECISION", 1)
     from deep_prior_interpolation_amd import _lib
-    _lib.load().dpi_set_bf16_debug(8)          # every 3x3x3 stride-1 conv through the bf16 kernel (by default only where it pays)
+    _lib.load().set_option("bf16_debug", 8)          # every 3x3x3 stride-1 conv through the bf16 kernel (by default only where it pays)
     gen = torch.Generator().manual_seed(cin * 1000 + cout)
     x = torch.randn((1, cin) + shape, generator=gen)
     w = torch.randn((cout, cin, k, k, k), generator=gen) * (1.0 / np.sqrt(cin * k ** 3))
@@ -758,7 +758,7 @@ def test_conv_bf16_mode_vs_oracle(ops, cin, cout, shape, k, monkeypatch):
     ops.raw_conv_bwd_data(d, dy.to(DEV), wg, acc, accumulate=True)
     plain = torch.empty_like(acc)
     ops.raw_conv_bwd_data(d, dy.to(DEV), wg, plain)
-    _lib.load().dpi_set_bf16_debug(0)
+    _lib.load().set_option("bf16_debug", 0)
     assert rel(acc, base + plain) < 1e-6
 
 
@@ -767,7 +767,7 @@ def test_conv_bf16_mode_chain_and_stats(ops, monkeypatch):
     from deep_prior_interpolation_amd import _lib
     monkeypatch.setattr(ops, "PRECISION", 1)
     L = _lib.load()
-    L.dpi_set_bf16_debug(8)
+    L.set_option("bf16_debug", 8)
     gen = torch.Generator().manual_seed(5)
     cin, cout, shape = 13, 9, (7, 12, 37)
     x = torch.randn((1, cin) + shape, generator=gen)
@@ -793,7 +793,7 @@ def test_conv_bf16_mode_chain_and_stats(ops, monkeypatch):
     yn = y.double().cpu().numpy()[0]
     np.testing.assert_allclose(p[:, 0], yn.reshape(cout, -1).sum(1), rtol=1e-9, atol=1e-7)
     np.testing.assert_allclose(p[:, 1], (yn.reshape(cout, -1) ** 2).sum(1), rtol=1e-9)
-    L.dpi_set_bf16_debug(0)
+    L.set_option("bf16_debug", 0)
 
 
 SPLIT_CASES = [(25, 16, (12, 9, 40), 3), (64, 4, (8, 12, 36), 3), (8, 13, (8, 8, 32), 3), (67, 4, (6, 10, 34), 3), (35, 71, (8, 8, 8), 3),
@@ -817,7 +817,7 @@ def test_conv_split_mode_has_fp32_accuracy(ops, cin, cout, shape, k, monkeypatch
     errs = {}
     for prec in (2, 0):
         monkeypatch.setattr(ops, "PRECISION", prec)
-        _lib.load().dpi_set_bf16_debug(8 if prec else 0)
+        _lib.load().set_option("bf16_debug", 8 if prec else 0)
         try:
             xg, wg = x.to(DEV), w.to(DEV)
             y = ops.conv(xg, wg, b.to(DEV), 1)
@@ -825,7 +825,7 @@ def test_conv_split_mode_has_fp32_accuracy(ops, cin, cout, shape, k, monkeypatch
             dx = torch.empty_like(xg)
             ops.raw_conv_bwd_data(d, dy.to(DEV), wg, dx)
         finally:
-            _lib.load().dpi_set_bf16_debug(0)
+            _lib.load().set_option("bf16_debug", 0)
         errs[prec] = (rel(y, yr), rel(dx, xr.grad))
     assert errs[2][0] < 2e-6 and errs[2][1] < 2e-6, errs
     assert errs[2][0] < 4 * errs[0][0] + 1e-7 and errs[2][1] < 4 * errs[0][1] + 1e-7, errs
@@ -873,7 +873,7 @@ def test_conv_bwd_weight_bf16_mode_vs_oracle(ops, cin, cout, shape, monkeypatch)
     from deep_prior_interpolation_amd import _lib
     monkeypatch.setattr(ops, "PRECISION", 1)
     L = _lib.load()
-    L.dpi_set_bf16_debug(8)
+    L.set_option("bf16_debug", 8)
     try:
         gen = torch.Generator().manual_seed(cin * 131 + cout)
         x = torch.randn((1, cin) + shape, generator=gen)
@@ -903,7 +903,7 @@ def test_conv_bwd_weight_bf16_mode_vs_oracle(ops, cin, cout, shape, monkeypatch)
         ops.raw_conv_bwd_weight(d, xg, cg, dyq.to(DEV), dwc)
         assert rel(dwc, wc.grad) < 5e-6
     finally:
-        L.dpi_set_bf16_debug(0)
+        L.set_option("bf16_debug", 0)
 
 
 @pytest.mark.parametrize("cin,cout,shape", BF16_BWW_CASES)
@@ -926,14 +926,14 @@ def test_conv_bwd_weight_split_mode_has_fp32_accuracy(ops, cin, cout, shape, mon
     errs = {}
     for prec in (2, 0):
         monkeypatch.setattr(ops, "PRECISION", prec)
-        _lib.load().dpi_set_bf16_debug(8 if prec else 0)      # every layer through the split kernel (by default only where it pays)
+        _lib.load().set_option("bf16_debug", 8 if prec else 0)      # every layer through the split kernel (by default only where it pays)
         try:
             d = ops.make_desc(xg, w.to(DEV), 1)
             assert d.precision == prec
             dw = torch.full_like(w, float("nan"), device=DEV)
             ops.raw_conv_bwd_weight(d, xg, cg, dyg, dw)
         finally:
-            _lib.load().dpi_set_bf16_debug(0)
+            _lib.load().set_option("bf16_debug", 0)
         errs[prec] = rel(dw, wr.grad)
     assert errs[2] < 5e-6, errs
     assert errs[2] < 4 * errs[0] + 1e-7, errs
@@ -1042,9 +1042,9 @@ Q4_CASES = [  # (cin, cout, shape): ragged depth / height / width tiles, 1..8 ou
 def q4_forced():
     from deep_prior_interpolation_amd import _lib
     L = _lib.load()
-    L.dpi_set_q4(2, 2)
+    L.set_option("q4", 2), L.set_option("q4_ck", 2)
     yield L
-    L.dpi_set_q4(1, 0)
+    L.set_option("q4", 1), L.set_option("q4_ck", 0)
 
 
 @pytest.mark.parametrize("ck", [2, 4])
@@ -1053,7 +1053,7 @@ def test_conv_q4_kernel_vs_oracle(ops, q4_forced, cin, cout, shape, ck):
     """csrc/conv_q4_mfma.hip (4x4x1 MFMA, <= 8 output channels) forced onto every shape it can run: forward with bias, and — through
     a convolution whose INPUT has <= 8 channels — backward-data, against the fp64 oracle; then bit-for-bit agreement of the default
     dispatch at these small sizes with what it was before (the kernel must not change results where it is not selected)."""
-    q4_forced.dpi_set_q4(2, ck)
+    q4_forced.set_option("q4", 2), q4_forced.set_option("q4_ck", ck)
     gen = torch.Generator().manual_seed(cin * 131 + cout)
     x = torch.randn((1, cin) + shape, generator=gen)
     w = torch.randn((cout, cin, 3, 3, 3), generator=gen) * (1.0 / np.sqrt(cin * 27))
@@ -1097,7 +1097,7 @@ def test_conv_q4_single_output_channel_kh_packed(ops, q4_forced, cin, shape):
     INPUT row, shifted sum in the epilogue): chain on load, bias, statistics, aligned and unaligned rows, ragged tile edges."""
     import ctypes as C
     L = q4_forced
-    L.dpi_set_q4(2, 4)
+    L.set_option("q4", 2), L.set_option("q4_ck", 4)
     gen = torch.Generator().manual_seed(5 + cin)
     x = torch.randn((1, cin) + shape, generator=gen)
     chain = torch.stack([torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen), torch.full((cin,), 0.2),

@@ -36,7 +36,7 @@ def _escape(snr, level=1.0):
 
 
 def _run_seed(seed, vol, mask, epochs, precision="fp32"):
-    from deep_prior_interpolation_amd import utils as u
+    from deep_prior_interpolation_amd import ops, utils as u
     from deep_prior_interpolation_amd.main import Interpolator
     from deep_prior_interpolation_amd.parameter import parse_arguments
     args = parse_arguments(["--imgdir", "synthetic", "--datadim", "3d", "--net", "multiunet", "--inputdepth", "64", "--upsample", "linear",
@@ -47,6 +47,8 @@ def _run_seed(seed, vol, mask, epochs, precision="fp32"):
     T.load_data({"image": (vol.astype(np.float64) * args.gain)[..., None], "mask": mask.astype(np.float64)[..., None], "name": "0"})
     T.build_model()
     T.build_input()
+    with T.precision_scope():
+        assert ops.storage_bf16() == (precision == "bf16")
     T.optimize(verbose=False)
     target = vol.astype(np.float64) * args.gain
     ob = np.asarray(T.out_best, dtype=np.float64)
@@ -98,12 +100,11 @@ def test_bf16_mode_stays_within_the_reference_distribution(precision):
     ref_snr, ref_min = z["snr_out_best"].astype(np.float64), z["loss_min"].astype(np.float64)
     # by default the mode only switches the shapes where the bf16 kernel is faster (none at this patch size): force EVERY 3x3x3
     # stride-1 convolution (forward and backward-data) through it, which is the harsher numerical test
-    _lib.load().dpi_set_bf16_debug(8)
+    _lib.load().set_option("bf16_debug", 8)
     try:
         got = [_run_seed(s, vol, mask, epochs, precision=precision) for s in range(12 if precision == "bf16" else 6)]
-        assert ops.STORAGE_BF16 == (precision == "bf16")
     finally:
-        _lib.load().dpi_set_bf16_debug(0)
+        _lib.load().set_option("bf16_debug", 0)
         ops.set_precision("fp32")
         ops.set_storage("fp32")
     snr, lmin = np.array([g[0] for g in got]), np.array([g[1] for g in got])
@@ -192,7 +193,6 @@ def test_mid_size_snr_matches_the_reference_at_big_tile_size(precision):
     assert ref.shape[0] >= 3 and n_it >= 600
     try:
         got = [_run_seed(s, vol, mask, n_it, precision=precision) for s in range(6)]
-        assert ops.STORAGE_BF16 == (precision == "bf16")
     finally:
         ops.set_precision("fp32")
         ops.set_storage("fp32")

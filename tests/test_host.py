@@ -345,3 +345,68 @@ def test_polyphase_identity_behind_design_section_7():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.main()
+
+
+# ---------------------------------------------------------------- parity mode: the reference's own input stream -----
+def _parity_interpolator(seed, vol, mask, argv_extra=(), param_noise=False, device="cpu"):
+    """An Interpolator prepared exactly as oracle/make_snr_spread.py prepares the reference's (u.set_seed -> Interpolator -> load_data ->
+    build_model -> build_input), with --noise_source torch_cpu.  device="cpu" only carries the HOST side (weights, z, the perturbed input):
+    the forward needs the HIP library."""
+    from deep_prior_interpolation_amd.main import Interpolator
+    args = parse_arguments(["--imgdir", "synthetic", "--datadim", "3d", "--net", "multiunet", "--inputdepth", "64", "--upsample", "linear",
+                            "--loss", "mae", "--lr", "1e-3", "--gain", "40", "--reg_noise_std", "0.03", "--noise_std", "0.1",
+                            "--noise_source", "torch_cpu"] + list(argv_extra))
+    args.param_noise = param_noise
+    u.set_seed(seed)
+    T = Interpolator(args, "/tmp", device=torch.device(device), seed=seed)
+    T.load_data({"image": (vol.astype(np.float64) * args.gain)[..., None], "mask": mask.astype(np.float64)[..., None], "name": "0"})
+    T.build_model()
+    T.build_input()
+    return T, args
+
+
+def test_torch_cpu_noise_source_reproduces_the_reference_stream():
+    """--noise_source torch_cpu must hand the network the reference's own iteration-0 input: same seed -> bit-identical initial weights
+    (test_same_seed_init_is_bit_identical), the same z and the same first perturbation, in the order of reference main.py:59-64,148-150.
+    Checked WITHOUT a GPU: the oracle's forward on that input against the iteration-0 loss / SNR / PCORR the reference itself recorded
+    (tests/golden/snr_spread.npz, oracle/make_snr_spread.py: 48x32x32, default 5.9 M-parameter net, seeds 0 and 1).  A wrong draw order
+    or a different z gives a different loss in the third digit (the seeds differ from each other by 3e-3)."""
+    from oracle import dpi_oracle as O
+    z = np.load(os.path.join(ROOT, "tests", "golden", "snr_spread.npz"))
+    assert str(z["torch"]) == torch.__version__, "the CPU generator's stream is pinned to the torch build that recorded the fixture"
+    vol, mask = z["volume"], z["mask"].astype(np.float32)
+    for k in (0, 1):
+        seed = int(z["seed"][k])
+        T, a = _parity_interpolator(seed, vol, mask)
+        inp = T.perturbed_input()
+        assert inp.shape == (1, 64) + vol.shape and not torch.equal(inp, T.input_)
+        S = O.NetState({n: v.detach().clone() for n, v in T.net.state_dict().items()})
+        with torch.no_grad():
+            out = O.net_forward(S, inp, {"ndim": 3, "filters": a.filters, "skip": a.skip, "upsample": "trilinear"})
+        loss = O.masked_loss(out, T.img_, T.mask_, "mae").item()
+        assert abs(loss - float(z["loss"][k, 0])) <= 1e-5 * abs(loss), (seed, loss, float(z["loss"][k, 0]))
+        assert abs(O.snr(out, T.img_).item() - float(z["snr"][k, 0])) < 1e-3
+        assert abs(O.pcorr(out, T.img_).item() - float(z["pcorr"][k, 0])) < 1e-4
+
+
+def test_torch_cpu_noise_source_draws_the_param_noise_the_reference_discards():
+    """With --param_noise (the CLI default) the reference draws one normal_() per 4-D / 5-D parameter before the input perturbation and throws
+    the result away (main.py:143-145): parity mode must move the generator by the same amount — and not touch the weights."""
+    vol = np.zeros((8, 8, 8), np.float32)
+    vol[2:5] = 1.0
+    mask = np.ones_like(vol)
+    small = ["--filters", "4", "8", "--skip", "4", "--inputdepth", "2"]
+    T, _ = _parity_interpolator(3, vol, mask, small, param_noise=True)
+    w0 = {n: v.clone() for n, v in T.net.state_dict().items()}
+    state = torch.get_rng_state()
+    got = T.perturbed_input()
+    torch.set_rng_state(state)
+    for p in T.net.parameters():
+        if p.ndim in (4, 5):
+            p.detach().clone().normal_()
+    want = T._z_cpu.clone()
+    want += 0.03 * want.clone().normal_()
+    assert torch.equal(got, want)
+    assert all(torch.equal(v, w0[n]) for n, v in T.net.state_dict().items())
+    T2, _ = _parity_interpolator(3, vol, mask, small, param_noise=False)
+    assert torch.equal(T2._z_cpu, T._z_cpu) and not torch.equal(T2.perturbed_input(), got)

@@ -47,17 +47,22 @@ def main():
     a = ap.parse_args()
     L = _lib.load()
     if a.mfma_min_cout is not None:
-        L.dpi_set_mfma_min_cout(a.mfma_min_cout)
+        L.set_option("mfma_min_cout", a.mfma_min_cout)
     if a.bw_mfma_min_cout is not None:
-        L.dpi_set_bwd_weight_mfma_min_cout(a.bw_mfma_min_cout)
-    L.dpi_set_bw_tuning(a.bw_want, a.bw_xcd)
-    L.dpi_set_q4(a.q4, a.q4_ck)
+        L.set_option("bwd_weight_mfma_min_cout", a.bw_mfma_min_cout)
+    if a.bw_want > 0:
+        L.set_option("bw_workgroups", a.bw_want)
+    if a.bw_xcd >= 0:
+        L.set_option("bw_xcd_order", a.bw_xcd)
+    if a.q4 >= 0:
+        L.set_option("q4", a.q4)
+    if a.q4_ck in (0, 2, 4):
+        L.set_option("q4_ck", a.q4_ck)
     if a.q4_debug:
-        L.dpi_set_q4_debug(a.q4_debug)
+        L.set_option("q4_debug", a.q4_debug)
     ops.set_precision(a.precision)
     if a.bf16_debug:
-        L.dpi_set_bf16_debug.argtypes = [C.c_int]
-        L.dpi_set_bf16_debug(a.bf16_debug)
+        L.set_option("bf16_debug", a.bf16_debug)
     dev = "cuda"
     print("%-16s %-10s %10s %9s %8s" % ("case", "kernel", "ms", "TFLOP/s", "GB/s(alg)"))
     for name in a.cases:
