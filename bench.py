@@ -56,7 +56,7 @@ FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA
 FP32_SUSTAINED_TFLOPS = 154.0     # tools/ubench/mfma_rate: pure v_mfma_f32_16x16x4_f32 stream, 32.25 clk/MFMA at 2.39 GHz
 HBM_PEAK_GBS = 8000.0
 # rocprofv3 --pmc results (cannot be collected in-process); each carries the digest of the kernel sources it was collected on
-PROFILE_JSON = {"fp32": os.path.join(ROOT, "profiles", "r05_traffic.json"), "bf16": os.path.join(ROOT, "profiles", "r05_bf16_traffic.json")}
+PROFILE_JSON = {"fp32": os.path.join(ROOT, "profiles", "r06_traffic.json"), "bf16": os.path.join(ROOT, "profiles", "r06_bf16_traffic.json")}
 
 
 def parse():

@@ -1211,6 +1211,42 @@ __global__ __launch_bounds__(256) void conv_bwd_data_s2_mfma_kernel(BdS2Args a) 
         }
   }
   // ---- store: D row = ci (4*lk + r), D col = m column lj ---------------------------------------------------------------
+  // Round 6: the two column-parity classes of a position are NEIGHBOURS in dx (iw = 2 m and 2 m + 1): stored (and, with `accumulate`, read) as
+  // one float2 per lane — 16 lanes cover a whole 128-byte line instead of every second float of it twice — with all reads of a row issued
+  // before the first store.  The gradient fan-in of an encoder output (ops.FanIn) runs through this read-modify-write.  Rows of odd length (or
+  // bf16 storage) keep the scalar form.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const bool vec2 = !a.dxb && ((a.W | (int)(V & 1)) & 1) == 0 && (((uintptr_t)a.dx) & 7) == 0;      // wave-uniform
+  if (vec2) {
+#pragma unroll
+    for (int cp = 0; cp < NCLS / 2; ++cp) {
+      const int ph = cp & 1, pd = KD == 3 ? (cp >> 1) & 1 : 0;
+#pragma unroll
+      for (int row = 0; row < 2; ++row) {
+        const int id = KD == 3 ? 2 * md0 + pd : md0, ih = 2 * (mh0 + wid * 2 + row) + ph, iw = 2 * (mw0 + lj);
+        if (id < a.D && ih < a.H && iw < a.W) {
+          f32x2 old[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ci = n0 + 4 * lk + r;
+            const size_t o = (size_t)min(ci, a.Cin - 1) * V + ((size_t)id * a.H + ih) * a.W + iw;
+            old[r] = a.accumulate ? *reinterpret_cast<const f32x2*>(a.dx + o) : (f32x2){0.f, 0.f};
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ci = n0 + 4 * lk + r;
+            if (ci < a.Cin) {
+              const size_t o = (size_t)ci * V + ((size_t)id * a.H + ih) * a.W + iw;
+              const f32x2 v = a.accumulate ? (f32x2){old[r][0] + acc[2 * cp][row][r], old[r][1] + acc[2 * cp + 1][row][r]}
+                                           : (f32x2){acc[2 * cp][row][r], acc[2 * cp + 1][row][r]};
+              *reinterpret_cast<f32x2*>(a.dx + o) = v;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int cls = 0; cls < NCLS; ++cls) {
     const int pw = cls & 1, ph = (cls >> 1) & 1, pd = KD == 3 ? (cls >> 2) & 1 : 0;

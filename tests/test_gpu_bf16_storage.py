@@ -784,3 +784,71 @@ def test_configs4_field_scale_job_end_to_end(ops, monkeypatch):
           % (err, float(np.abs(ref).max())))
     assert err <= 2e-6 * float(np.abs(ref).max())        # fp32 sums of <= 4 patch values against float64
     torch.cuda.empty_cache()
+
+
+def test_whole_net_in_storage_mode_against_the_fp64_oracle_with_the_same_rounding_points(ops, monkeypatch):
+    """the net-level bf16 tests compared HIP with HIP.  Here the ORACLE (fp64 arithmetic) is given the rounding points of the
+    storage mode and the HIP net must land on it.  Rounding points of `--precision bf16` on the 3-D MultiRes-UNet (every 3x3x3 layer
+    forced through the bf16 kernels — `bf16_debug` bit 3 — so that the operand roundings do not depend on the `bf16_pays` table):
+      * every tensor a fused node STORES is bf16: raw conv outputs (bias added), the stride-2 layer's activation, block / ResPath outputs, the up-sampled
+        deep branch (both halves of a level's concat buffer), the network input; the output layer writes fp32;
+      * a 3x3x3 layer (stride 1 or 2) rounds BOTH matrix operands to bf16 — the chained input T(stored) and the weights; a 1x1x1 layer multiplies the
+        stored (bf16) input with fp32 weights on the fp32 MFMA;
+      * BatchNorm statistics are those of the stored values; chains, joins, sums, loss: fp32 (the oracle: fp64).
+    The oracle with these roundings differs from the exact fp64 oracle by the whole effect of the storage type (printed: ~1e-2 of the output); the HIP
+    net must agree with the EMULATED oracle an order of magnitude better than that — a missing or misplaced rounding point in either shows up as an
+    error of the size of the effect itself.  What remains is fp32 accumulation nudging a value across a bf16 rounding boundary here and there."""
+    from oracle import dpi_oracle as O
+    shape = (32, 32, 64)
+    extra = ["--filters", "16", "32", "64", "--skip", "16", "32"]
+    T = _net_run(shape, "bf16", 1, extra=extra, inputdepth=16)
+    assert T.storage_bf16_ok()
+    init = {k: v.detach().cpu().clone() for k, v in T.net.state_dict().items()}
+    gen = torch.Generator().manual_seed(11)
+    x = (0.1 * torch.randn((1, 16) + shape, generator=gen)).to(BF).float()               # the stored network input
+    cfg = {"ndim": 3, "filters": T.args.filters, "skip": T.args.skip, "upsample": "trilinear"}
+    img, msk = T.img_.cpu().double(), T.mask_.cpu().double()
+    rb = lambda t: t.to(BF).to(t.dtype)                                                   # round to nearest-even, identity gradient
+
+    class StorageState(O.NetState):
+        def conv(self, key, xin, stride=1):
+            self.used.update((key + ".weight", key + ".bias"))
+            w, b = self.P[key + ".weight"], self.P.get(key + ".bias")
+            xin = rb(xin)                                                                 # a stored tensor (no-op) or the bf16 MFMA operand T(stored)
+            if w.shape[-1] == 3:
+                w = rb(w)                                                                 # 3x3x3: both operands on the bf16 MFMA
+            y = O.conv_nd(xin, w, b, stride)
+            return y if key == "4.0" else rb(y)                                           # the output layer writes fp32
+    exact = O.NetState(init, dtype=torch.float64)
+    o_exact = O.net_forward(exact, x.double(), cfg).detach()
+    for name in ("block3d", "respath3d", "upsample2x"):                                    # block / ResPath outputs and the up-sampled branch are stored
+        orig = getattr(O, name)
+        monkeypatch.setattr(O, name, (lambda f: (lambda *a, **k: rb(f(*a, **k))))(orig))
+    emu = StorageState(init, dtype=torch.float64)
+    o_emu = O.net_forward(emu, x.double(), cfg)
+    l_emu = O.masked_loss(o_emu, img, msk, "mae")
+    l_emu.backward()
+    L = ops._lib.load()
+    L.set_option("bf16_debug", 8)
+    try:
+        T.optimize(net_inputs=[x.to(DEV).to(BF)], verbose=False)
+    finally:
+        L.set_option("bf16_debug", 0)
+    out = torch.from_numpy(np.asarray(T.out_best, dtype=np.float64))[None, None]
+    nrm = lambda a, b: float((a - b).norm() / b.norm())
+    effect, err = nrm(o_emu.detach(), o_exact), nrm(out, o_emu.detach())
+    print("storage-mode effect on the output (emulated vs exact fp64 oracle) %.3e; HIP vs emulated oracle %.3e; HIP vs exact %.3e; loss HIP %.6f emulated %.6f"
+          % (effect, err, nrm(out, o_exact), T.history.loss[0], l_emu.item()))
+    assert effect > 2e-3                                                                  # the roundings are not a no-op at this size
+    assert err < 0.2 * effect, (err, effect)
+    assert abs(T.history.loss[0] - l_emu.item()) < 0.2 * effect * abs(l_emu.item()) + 1e-6
+    # weight gradients: the HIP path also STORES activation gradients as bf16 (the emulation passes gradients through unrounded): same direction, same size
+    cos, big = [], 0
+    for k, p in T.net.named_parameters():
+        if p.ndim == 5 and p.grad is not None:
+            g, ge = p.grad.detach().cpu().double().flatten(), emu.P[k].grad.flatten()
+            if ge.norm() > 0:
+                cos.append(float(torch.dot(g, ge) / (g.norm() * ge.norm() + 1e-300)))
+                big += 1
+    print("conv-weight gradients vs the emulated oracle: cosine min %.4f median %.4f over %d tensors" % (min(cos), float(np.median(cos)), big))
+    assert np.median(cos) > 0.98 and min(cos) > 0.85

@@ -162,6 +162,62 @@ def test_full_size_net_one_step_vs_oracle():
     assert worst < 1e-2, worst
 
 
+def test_configs2_patch_one_step_vs_oracle():
+    """BASELINE configs[2]'s unit of work — one 64^3 patch of the 256^3 volume through the DEFAULT 5.9 M-parameter net, 64-channel input, MAE, trilinear
+    (`bench.py`'s `configs2` / `gpu_same_sample` run exactly this) — against the CPU oracle on the same weights and input: output, loss, SNR
+    and PCORR of iteration 0 against the fp64 oracle, every conv-weight gradient in the same error class as the oracle's own fp32 run, and the weights
+    after ONE Adam step against the oracle's step on its fp64 gradients (5e-3 of lr on a norm-wise scale: the first step is ~lr * sign(g))."""
+    from deep_prior_interpolation_amd import ops, utils as u
+    from deep_prior_interpolation_amd.main import Interpolator
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    from oracle import dpi_oracle as O
+    a = parse_arguments(["--imgdir", "x", "--datadim", "3d", "--upsample", "linear", "--loss", "mae", "--gain", "40", "--epochs", "1", "--gpu", "0"])
+    vol = u.hyperbolic_volume((256, 256, 256), seed=0)[96:160, 64:128, 128:192]             # one window of the configs[2] volume
+    mask = u.random_trace_mask((64, 64, 64), 0.5, seed=1)
+    u.set_seed(0)
+    T = Interpolator(a, "/tmp", seed=0)
+    T.load_data({"image": (vol.astype(np.float64) * a.gain)[..., None], "mask": mask.astype(np.float64)[..., None], "name": "0"})
+    T.build_model()
+    init = {k: v.detach().cpu().clone() for k, v in T.net.state_dict().items()}
+    gen = torch.Generator().manual_seed(3)
+    x = 0.1 * torch.randn((1, 64, 64, 64, 64), generator=gen) + 0.03 * torch.randn((1, 64, 64, 64, 64), generator=gen)
+    cfg = {"ndim": 3, "filters": a.filters, "skip": a.skip, "upsample": "trilinear"}
+    img, msk = T.img_.cpu(), T.mask_.cpu()
+
+    def oracle(dtype):
+        S = O.NetState(init, dtype=dtype)
+        out = O.net_forward(S, x.to(dtype), cfg)
+        loss = O.masked_loss(out, img.to(dtype), msk.to(dtype), "mae")
+        loss.backward()
+        return S, out.detach(), loss.item()
+    S64, o64, l64 = oracle(torch.float64)
+    S32, o32, _ = oracle(torch.float32)
+    T.optimize(net_inputs=[x.to(DEV)], verbose=False)
+    assert abs(T.history.loss[0] - l64) <= 1e-5 * abs(l64)
+    assert abs(T.history.snr[0] - O.snr(o64, img.double()).item()) < 1e-3
+    assert abs(T.history.pcorr[0] - O.pcorr(o64, img.double()).item()) < 1e-4
+    assert rel(T.out_best, o64[0, 0].numpy()) < 5e-5
+    ratios, worst = [], 0.0
+    for k, p in T.net.named_parameters():
+        if p.ndim > 1:
+            g64 = S64.P[k].grad.numpy()
+            e_gpu, e_cpu = rel(p.grad, g64), rel(S32.P[k].grad, g64)
+            ratios.append(e_gpu / max(e_cpu, 1e-12))
+            worst = max(worst, e_gpu)
+    assert np.median(ratios) < 2.0 and worst < 2e-2, (np.median(ratios), worst)
+    # one Adam step from zero moments moves every weight by lr * g / (|g| + eps): compare where the oracle's gradient is clear of eps and of its own rounding
+    moved = 0
+    for k, p in T.net.named_parameters():
+        if p.ndim > 1:
+            g = S64.P[k].grad
+            want = init[k].double() - a.lr * g / (g.abs() + 1e-8)
+            clear = (g.abs() > 1e-6) & ((S32.P[k].grad.double() - g).abs() < 0.05 * g.abs())
+            if clear.any():
+                moved += int(clear.sum())
+                assert float((p.detach().cpu().double() - want)[clear].abs().max()) < 0.1 * a.lr, k
+    assert moved > 1e5, moved
+
+
 def test_graph_mode_matches_eager(golden):
     """The hipGraph-captured loop (device-resident history / best tracking / Adam gating) reproduces the eager loop
     bit for bit: same Philox noise stream, same kernels, same order."""
@@ -394,17 +450,24 @@ def test_branch_stream_schedule_is_bit_identical_to_the_serial_one(monkeypatch, 
         torch.cuda.synchronize()
         return (np.array(T.history.loss), np.array(T.history.snr), T.out_best.copy(),
                 {k: v.detach().cpu().numpy().copy() for k, v in T.net.state_dict().items()})
+    def same(r0, r1):
+        (l0, s0, o0, w0), (l1, s1, o1, w1) = r0, r1
+        np.testing.assert_array_equal(l0, l1)
+        np.testing.assert_array_equal(s0, s1)
+        np.testing.assert_array_equal(o0, o1)
+        assert sorted(w0) == sorted(w1)
+        for k in w0:
+            np.testing.assert_array_equal(w0[k], w1[k], err_msg=k)
     try:
-        l0, s0, o0, w0 = run("node", False, False)
-        for k in range(4):          # a race need not show up in every run; the last run: the serial schedule with the fused fan-in
-            l1, s1, o1, w1 = run("step", True, True) if k < 3 else run("node", False, True)
+        serial = {fan: run("node", False, fan) for fan in (False, True)}       # the serial schedule, autograd's add pass / the fused fan-in
+        if precision == "fp32":
+            same(serial[False], serial[True])        # old + new in the kernel epilogue IS the add pass's sum (bf16 storage: one rounding less, see ops.FanIn)
+        for k in range(4):          # a race need not show up in every run; the last run: the streams without the fused fan-in
+            fan = k < 3
+            got = run("step", True, fan)
             assert ops.OVERLAP_WEIGHT_GRADS and not ops._in_iteration[0] and not ops._side_keep
-            np.testing.assert_array_equal(l0, l1)
-            np.testing.assert_array_equal(s0, s1)
-            np.testing.assert_array_equal(o0, o1)
-            assert sorted(w0) == sorted(w1)
-            for k in w0:
-                np.testing.assert_array_equal(w0[k], w1[k], err_msg=k)
+            same(serial[fan], got)
+        l0 = serial[False][0]
     finally:
         ops.set_weight_grad_overlap(False)
         ops.set_precision("fp32")
@@ -449,6 +512,73 @@ def test_snr_parity_with_oracle_over_a_longer_run():
     assert abs(got[-10:].mean() - ref[-10:].mean()) < 0.08 * ref[-10:].mean()
     assert abs(max(T.history.snr) - max(h["snr"])) < 0.5
     assert np.abs(np.array(T.history.snr)[:10] - np.array(h["snr"])[:10]).max() < 0.02
+
+
+def test_interpolators_of_different_precision_share_a_concurrent_group_and_threads(tmp_path):
+    """--precision used to be module globals of `ops` flipped at the top of every iteration.  Now every iteration runs inside
+    the Interpolator's own ops.mode_scope (per host thread).  (1) An fp32, a bf16-storage and a bf16mm Interpolator in ONE optimize_concurrently group
+    (their graphs captured one after the other, replayed interleaved) each reproduce their solo run bit for bit.  (2) Two host threads driving an fp32
+    and a bf16-storage Interpolator eagerly at the same time — the case globals would race on — reproduce the solo runs too."""
+    import threading
+    from deep_prior_interpolation_amd import ops, utils as u
+    from deep_prior_interpolation_amd.main import Interpolator, optimize_concurrently
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    precs = ["fp32", "bf16", "bf16mm"]
+    vol = u.hyperbolic_volume((24, 16, 32), seed=3)[..., None] * 40.0
+    mask = u.random_trace_mask((24, 16, 32), 0.5, seed=9)[..., None].astype(np.float64)
+
+    def prepared(prec, epochs=10):
+        args = parse_arguments(["--imgdir", "x", "--datadim", "3d", "--filters", "4", "8", "--skip", "4", "--inputdepth", "8", "--upsample", "linear",
+                                "--epochs", str(epochs), "--gpu", "0", "--precision", prec])
+        u.set_seed(1)
+        T = Interpolator(args, str(tmp_path), device=torch.device("cuda", 0), seed=1)
+        T.load_data({"image": vol, "mask": mask, "name": prec})
+        T.build_model()
+        T.build_input()
+        return T
+    solo = {}
+    for prec in precs:
+        S = prepared(prec)
+        S.optimize(verbose=False, mode="graph")
+        solo[prec] = (list(S.history.loss), S.out_best.copy())
+    assert solo["fp32"][0] != solo["bf16"][0] and solo["bf16"][0] != solo["bf16mm"][0]          # the modes really differ
+    group = [prepared(prec) for prec in precs]
+    optimize_concurrently(group)
+    for prec, T in zip(precs, group):
+        assert T.history.loss == solo[prec][0], prec
+        np.testing.assert_array_equal(T.out_best, solo[prec][1])
+    assert ops.precision() == 0 and not ops.storage_bf16()                      # nothing of any scope outlives it
+    # (2) two eager loops on two host threads (each on its own stream)
+    eager = {}
+    for prec in ("fp32", "bf16"):
+        S = prepared(prec, epochs=6)
+        S.optimize(verbose=False, mode="eager")
+        eager[prec] = list(S.history.loss)
+    got, errors = {}, []
+
+    def drive(prec):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                T = prepared(prec, epochs=6)
+                torch.cuda.current_stream().synchronize()
+                T.optimize(verbose=False, mode="eager")
+                got[prec] = list(T.history.loss)
+        except BaseException as e:                                              # noqa: BLE001 — reported by the asserting thread
+            errors.append((prec, repr(e)))
+    # set-up draws from torch's global CPU generator (set_seed): prepare sequentially, run concurrently
+    lock = threading.Lock()
+    orig_prepared = prepared
+
+    def prepared(prec, epochs=10):                                              # noqa: F811
+        with lock:
+            return orig_prepared(prec, epochs)
+    th = [threading.Thread(target=drive, args=(prec,)) for prec in ("fp32", "bf16")]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    assert got["fp32"] == eager["fp32"] and got["bf16"] == eager["bf16"]
 
 
 def test_concurrent_patches_match_standalone_graph_run(tmp_path, monkeypatch):

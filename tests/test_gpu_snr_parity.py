@@ -214,30 +214,16 @@ def test_mid_size_snr_matches_the_reference_at_big_tile_size(precision):
     assert max(_escape(s) for s in mine) < 200 and max(_escape(s) for s in ref) < 200
 
 
-# HIP's own seed-to-seed standard deviation at 256x128x128 (twelve seeds, profiles/r05/snr_head_hip6.json + snr_head_hip6_seeds6to11.json;
-# the first six alone gave 0.36-0.46 dB from iteration 220 on — too narrow): the spread the bars below are built from where the reference
-# recording has too few seeds to show its own
-HIP_HEAD_SD = {100: 1.81, 220: 0.71, 300: 0.54, 400: 0.61, 500: 0.62, 599: 0.47}
+_HEAD_CACHE = {}
+HEAD_CHECKPOINTS = (100, 220, 300, 400, 500, 599)
 
 
-def test_head_of_the_run_at_bench_geometry_against_the_reference():
-    """The bench geometry itself (256x128x128, BASELINE configs[1]) against the REFERENCE: tests/golden/snr_bench_head_256x128x128.npz holds the
-    heads of 3000-iteration runs of the reference's Interpolator on the notebook-like stand-in (oracle/make_snr_spread.py --mid 256 128 128:
-    3 CPU threads, ~60 s per iteration; seed 0: 625 iterations recorded in round 4; seeds 1 and 2 recorded in the background of round 5 as far
-    as the round lasted — `iterations` in the file says how far each got; every checkpoint is compared over the seeds that reached it).
-    Here: the HIP path on the same volume and mask, seeds 0..5, for as many iterations (at most 600).
-    Bars: from the measured spreads — at every checkpoint from iteration 220 on the difference of the means must
-    be within max(3 s.e., 1 dB), s.e. from HIP's seed-to-seed standard deviation at this size (HIP_HEAD_SD, twelve seeds) and the reference's
-    own (never taken below HIP's) once >= 3 reference seeds cover the checkpoint; where fewer do, ONE draw cannot pin a distribution, so the
-    reference's spread is taken to be HIP's and the bar is the round-4 one (4.5 dB at 220, 3 dB from 300 on) with the tight one printed beside it.
-    State of the recordings (`python tools/snr_head_summary.py`): three reference seeds to iteration 600 — 13.1 / 15.3 / 15.3 dB at 220,
-    15.4 / 16.7 / 16.4 at 300, 17.4 / 18.5 / 17.9 at 500, 18.2 / 17.8 / 18.8 at 599 — against twelve HIP seeds at 15.62 +- 0.71 / 16.97 +- 0.54 / 18.72 +- 0.62 /
-    19.57 +- 0.47: +1.07 dB (1.4 s.e.) / +0.77 (1.8 s.e.) / +0.78 (2.1 s.e.) / +1.30 (3.8 s.e.).  The HIP path LEADS the reference at this size by 0.5-1.3 dB through
-    the first 600 iterations, significantly so at the last checkpoint; the cause is not known (not the noise generator, the schedule or the kernel family:
-    bf16 storage, a different set of convolution kernels, follows the fp32 HIP curve) and one level below (128x64x64, 12 + 9 seeds) the two agree to 0.17 dB.
-    The assertion therefore holds a DEFICIT to the tight bar and a lead to the round-4 bar; DESIGN §4 states the lead as an open difference.  Seed 0, the only
-    draw round 4 had, is the slow one.  With the perturbation drawn by torch's generator instead of dpi_noise_add the HIP curve is the same
-    (profiles/r05/snr_head_hip3_torch_noise.json); at 128x64x64 twelve HIP seeds and nine reference seeds agree to 0.17 dB at every checkpoint."""
+def _head_comparison():
+    """Six HIP seeds (0..5) at 256x128x128 for as many iterations as the reference recording covers (at most 600) and, per checkpoint, the
+    textbook two-sample comparison with the reference seeds that reached it: difference of the means of the 11-iteration window averages and its
+    standard error from the two SAMPLE standard deviations (Welch) — no hard-coded spreads, no floors.  Run once per session (~2 minutes)."""
+    if _HEAD_CACHE:
+        return _HEAD_CACHE
     import hashlib
     from deep_prior_interpolation_amd import utils as u
     z = np.load(os.path.join(os.path.dirname(GOLD), "snr_bench_head_256x128x128.npz"))
@@ -249,31 +235,63 @@ def test_head_of_the_run_at_bench_geometry_against_the_reference():
     assert hashlib.sha1(mask.astype(np.uint8).tobytes()).hexdigest() == str(z["mask_sha1"])
     ref = z["snr"].astype(np.float64)                       # [seed][iteration]; a seed recorded less far is padded with NaN (`iterations`)
     its = np.asarray(z["iterations"]).astype(int)
-    n_it = min(int(its.max()), 600)
-    assert ref.shape[0] >= 1 and n_it >= 220
+    n_it = min(int(np.sort(its)[-3]) if len(its) >= 3 else int(its.max()), 600)     # as far as at least three reference seeds got
+    assert ref.shape[0] >= 3 and n_it >= 220
     got = [_run_seed(s, vol, mask, n_it) for s in range(6)]
     mine = np.stack([g[2] for g in got])
-    esc_ref = [_escape(r[:n]) for r, n in zip(ref, its) if n >= 150]
-    esc_mine = [_escape(m) for m in mine]
-    print("plateau ends at iteration: reference %s, HIP %s; iterations recorded per reference seed: %s" % (esc_ref, esc_mine, its))
+    rows = []
+    for it in [i for i in HEAD_CHECKPOINTS if i < n_it]:
+        cover = [k for k in range(ref.shape[0]) if its[k] > it]         # the reference seeds that reached this checkpoint
+        a, b = mine[:, it - 10:it + 1].mean(axis=1), ref[cover, it - 10:it + 1].mean(axis=1)
+        se = float(np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b)))
+        rows.append(dict(it=it, hip=float(a.mean()), ref=float(b.mean()), n_hip=len(a), n_ref=len(b), sd_hip=float(a.std(ddof=1)), sd_ref=float(b.std(ddof=1)),
+                         diff=float(a.mean() - b.mean()), se=se, bar=max(3.0 * se, 1.0), ref_values=np.round(b, 2)))
+    for r in rows:
+        print("iteration %4d: SNR HIP %.2f +- %.2f dB (n=%d), reference %.2f +- %.2f dB (n=%d: %s): difference %+.2f dB = %.1f s.e. (s.e. %.2f), bar max(3 s.e., 1 dB) = %.2f"
+              % (r["it"], r["hip"], r["sd_hip"], r["n_hip"], r["ref"], r["sd_ref"], r["n_ref"], r["ref_values"], r["diff"], abs(r["diff"]) / r["se"], r["se"], r["bar"]))
+    _HEAD_CACHE.update(rows=rows, mine=mine, ref=ref, its=its, n_it=n_it)
+    return _HEAD_CACHE
+
+
+def test_head_of_the_run_at_bench_geometry_is_not_behind_the_reference():
+    """The bench geometry itself (256x128x128, BASELINE configs[1]) against the REFERENCE: tests/golden/snr_bench_head_256x128x128.npz holds the heads of
+    3000-iteration runs of the reference's Interpolator on the notebook-like stand-in (oracle/make_snr_spread.py --mid 256 128 128: 3 CPU threads, ~60 s
+    per iteration; seed 0 recorded in round 4, seeds 1 and 2 in round 5, seeds 3 and 4 in round 6 — `iterations` says how far each got; a checkpoint is
+    compared over the seeds that reached it).  Here: the HIP path on the same volume and mask, seeds 0..5.
+    THIS test holds what a user of the drop-in needs: the HIP path leaves the all-zero plateau when the reference does, every run is finite, and at no
+    checkpoint from iteration 220 on is it BEHIND the reference by more than max(3 s.e., 1 dB) (s.e. from the two sample spreads).  The symmetric
+    statement — parity, not just "no worse" — is the next test."""
+    c = _head_comparison()
+    esc_ref = [_escape(r[:n]) for r, n in zip(c["ref"], c["its"]) if n >= 150]
+    esc_mine = [_escape(m) for m in c["mine"]]
+    print("plateau ends at iteration: reference %s, HIP %s; iterations recorded per reference seed: %s" % (esc_ref, esc_mine, c["its"]))
     assert all(e > 0 for e in esc_ref + esc_mine)
     assert np.mean(esc_ref) / 2.5 <= np.mean(esc_mine) <= np.mean(esc_ref) * 2.5
-    for it in [i for i in (100, 220, 300, 400, 500, 599) if i < n_it]:
-        cover = [k for k in range(ref.shape[0]) if its[k] > it]         # the reference seeds that reached this checkpoint
-        n_ref = len(cover)
-        a, b = mine[:, it - 10:it + 1].mean(axis=1), ref[cover, it - 10:it + 1].mean(axis=1)
-        sd_h = HIP_HEAD_SD[it]
-        sd_r = max(float(b.std(ddof=1)), sd_h) if n_ref >= 3 else sd_h     # three draws under-estimate a spread as often as not: never below HIP's own
-        se = np.sqrt(sd_h ** 2 / len(a) + sd_r ** 2 / n_ref)
-        tight = max(3.0 * se, 1.0)
-        bar = tight if n_ref >= 3 else (4.5 if it < 300 else 3.0)
-        print("iteration %4d: SNR HIP %.2f dB (n=%d), reference %.2f dB (n=%d: %s): difference %+.2f dB, s.e. %.2f, max(3 s.e., 1 dB) = %.2f, asserted bar %.2f"
-              % (it, a.mean(), len(a), b.mean(), n_ref, np.round(b, 2), a.mean() - b.mean(), se, tight, bar))
-        if it >= 220:
-            # a DEFICIT of the HIP path is held to the bar from the spreads; a LEAD is what the recordings show at this size (+0.5 ... +1.3 dB,
-            # docstring) and is held to the round-4 bar only — the tight bar is printed above either way
-            assert b.mean() - a.mean() <= bar, (it, a.mean(), b.mean(), bar)
-            assert a.mean() - b.mean() <= max(bar, 4.5 if it < 300 else 3.0), (it, a.mean(), b.mean(), bar)
+    for r in c["rows"]:
+        if r["it"] >= 220:
+            assert r["ref"] - r["hip"] <= r["bar"], r
+
+
+HEAD_PARITY_XFAIL = None      # set below from the state of the recordings at the end of round 6 (see the docstring); None = the assertion simply holds
+
+
+def test_head_of_the_run_at_bench_geometry_matches_the_reference_both_ways():
+    """The SYMMETRIC bar (VERDICT / ADVICE round 5: a lead is a difference too): |difference of the means| <= max(3 s.e., 1 dB) at every checkpoint
+    from iteration 220 on, s.e. from the sample standard deviations of the six HIP runs and of the reference seeds covering the checkpoint.
+    What is known (`python tools/snr_head_summary.py`): with reference seeds 0..2 the HIP path LEADS by 0.5-1.3 dB through the first 600
+    iterations (12 HIP seeds: +1.30 dB = 3.8 s.e. at iteration 599; +1.1 / +0.8 / +0.5 / +0.8 at 220 / 300 / 400 / 500).  Round 6 looked for a cause
+    and excluded, one by one (27 further HIP runs, profiles/r06/): the network itself — iteration 0 of the assembled net at this size equals the
+    reference's recorded loss to 5e-8 with the reference's own z and perturbation, iteration 1 to 1e-3 (tests/test_gpu_bench_size.py) —, the ~3.3 k
+    dead conv biases the reference Adam-steps on rounding residues (`--dead-bias sum` / `noise`: same curve, +1.4 dB at 599), z from another
+    generator and the reference's OWN z and initial weights per seed (`--z torch_cpu`: +0.9 ... +1.3), the per-iteration noise generator and the
+    stream schedule (round 5), fp32 accuracy of the CPU's weight gradients at this size (3.7e-5 norm-wise).  Paired runs show that the spread is
+    chaotic, not seed-borne (0.5 dB between runs that share weights and z, 0.3 dB between seeds), so every reference run is one draw of ~0.5 dB:
+    seed 0 sits 2-3 such deviations low throughout, seeds 1 and 2 about one."""
+    c = _head_comparison()
+    over = [r for r in c["rows"] if r["it"] >= 220 and abs(r["diff"]) > r["bar"]]
+    if over and HEAD_PARITY_XFAIL:
+        pytest.xfail(HEAD_PARITY_XFAIL + " — this run: " + "; ".join("iteration %d: %+.2f dB (bar %.2f)" % (r["it"], r["diff"], r["bar"]) for r in over))
+    assert not over, over
 
 
 def test_full_length_run_at_bench_geometry():

@@ -39,7 +39,8 @@ def family(path):
         else:
             m = re.match(r"\s+(\w+)\s+n=(\d+) avg=([\d.e+]+)", line)
             if m and m.group(1) in ("FETCH_SIZE", "WRITE_SIZE") and key and (
-                    re.search(r"conv_bwd_weight_mfma(_merged|_pair)?_kernel<3, 1, 8, 2", key) or "smallco" in key):
+                    re.search(r"conv_bwd_weight_mfma(_merged|_pair)?_kernel<3, 1, 8, 2", key) or "smallco" in key
+                    or "conv_bf16_bwd_weight_kernel" in key):
                 rows.append((key, int(m.group(2)), float(m.group(3))))
     return rows
 
@@ -47,6 +48,11 @@ def family(path):
 f_it, f_k = totals(pre + "_hbm_iteration_FETCH_SIZE.txt")
 w_it, w_k = totals(pre + "_hbm_iteration_WRITE_SIZE.txt")
 fam_f, fam_w = family(pre + "_family_FETCH_SIZE.txt"), family(pre + "_family_WRITE_SIZE.txt")
+if not fam_f or not fam_w or not f_k or not w_k:
+    # (the bf16 family files of round 5 were empty — the --match filter of the collecting step named the fp32 kernels — and the
+    #  JSON was written all the same)
+    sys.exit("make_traffic_json: empty counter input (%d / %d family rows, %d / %d kernels in the whole-iteration breakdown) under prefix %s — "
+             "re-run the pmc_iter step (tools/profile_r06.sh; FAMILY_MATCH selects the backward-weight kernels by name)" % (len(fam_f), len(fam_w), len(f_k), len(w_k), pre))
 n_launch = sum(n for _, n, _ in fam_f)
 fam_read = sum(n * v for _, n, v in fam_f) * 1024.0 * 2.0
 fam_write = sum(n * v for _, n, v in fam_w) * 1024.0
