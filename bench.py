@@ -99,18 +99,17 @@ def parse():
 PRECISION = "fp32"
 WGRAD_OVERLAP = os.environ.get("DPI_BENCH_WGRAD_OVERLAP", "1") == "1"     # weight gradients on a side stream (eager, patches >= 2^20 voxels)
 # the metric's second half; numbers from tests/test_gpu_snr_parity.py on the committed reference recordings
-SNR_STATEMENT = ("SNR(out_best) HIP vs the reference's own Interpolator, same volume / mask / hyper-parameters: "
-                 "+0.00 dB +- 0.35 (2 s.e., n = 12 + 9) at 128x64x64 on the notebook-like stand-in, 1200 iterations — the smallest volume that "
-                 "runs the bench patch's kernel variants (tests/golden/snr_mid_128x64x64.npz: reference 23.52 +- 0.46 dB, HIP 23.52 +- 0.31; mean "
-                 "trajectories within 0.17 dB at iterations 220..1199; bf16 storage at that size: -0.03 dB +- 0.36, n = 6); +0.22 dB +- 0.34 (2 s.e., n = 48 + 48) "
-                 "at 48x32x32, 1000 iterations (tests/golden/snr_spread.npz).  All within the reference's own seed-to-seed spread (0.3-0.9 dB), not "
-                 "resolvable to 0.1 dB.  At 256x128x128: twelve HIP seeds (15.6 / 17.0 / 18.0 / 18.7 / 19.6 dB at iterations 220 / 300 / 400 / 500 / 599, "
-                 "s.d. 0.5-0.7 dB) against the three reference seeds recorded to iteration 600 (13.1 / 15.3 / 15.3 dB at 220, 15.4 / 16.7 / 16.4 at 300, 17.4 / 18.5 / 17.9 at 500, "
-                 "18.2 / 17.8 / 18.8 at 599): +1.1 dB = 1.4 s.e. at 220, +0.8 dB = 1.8 s.e. at 300, +0.5 dB = 2.0 s.e. at 400, +0.8 dB = 2.1 s.e. at 500, +1.3 dB = 3.8 s.e. at 599 — "
-                 "the HIP path LEADS the reference by 0.5-1.3 dB through the first 600 iterations at this size: a difference, not parity; not a deficit; cause unknown "
-                 "(tests/golden/snr_bench_head_256x128x128.npz; python tools/snr_head_summary.py); the noise generator, the stream schedule and the kernel family "
-                 "are excluded as causes (DESIGN.md §4); complete 3000-iteration HIP runs "
-                 "reach 24.5-25.0 dB (profiles/r03, profiles/r04 full_run_*.json)")
+SNR_STATEMENT = ("HIP vs the reference's own Interpolator, same volume / mask / hyper-parameters / seeds (bit-identical initial weights).  AT THIS GEOMETRY (256x128x128): "
+                 "iteration 0 of the assembled net equals the reference's recorded loss to 5e-8 (relative) given the reference's own z and perturbation, iteration 1 to 1e-3 "
+                 "(tests/test_gpu_bench_size.py: --noise_source torch_cpu); over the heads of the runs (600 iterations; a reference iteration costs a minute of CPU) 39 HIP runs "
+                 "LEAD reference seeds 0-2 by +1.1 / +0.8 / +0.6 / +0.9 / +1.2 dB at iterations 220 / 300 / 400 / 500 / 599 (1.5-3.9 s.e. with ~2 Welch degrees of freedom: p ~ 0.05; "
+                 "reference seeds 3-5 were being recorded when round 6 ended: `python tools/snr_head_summary.py` prints the comparison with whatever tests/golden/"
+                 "snr_bench_head_256x128x128.npz holds) — a difference, not parity; not a deficit; NO CAUSE FOUND: excluded in round 6 are the network itself (the iteration-0 pin), "
+                 "the dead conv biases the reference Adam-steps, z (incl. paired runs on the reference's own z and weights), the noise generator, the stream schedule, Adam and the "
+                 "fp32 accuracy of the CPU's gradients (DESIGN.md §4).  One level below (128x64x64, 1200 iterations, the smallest volume that runs this patch's kernel variants): "
+                 "SNR(out_best) +0.00 dB +- 0.35 (2 s.e., n = 12 + 9; bf16 storage -0.03 +- 0.36); 48x32x32, 1000 iterations: +0.21 dB +- 0.35 (n = 48 + 48).  north_star's 0.1 dB is "
+                 "BELOW THE RESOLUTION of every one of these samples (s.e. of a difference 0.17-0.35 dB; the reference's own seed-to-seed spread is 0.3-0.9 dB).  Complete "
+                 "3000-iteration HIP runs at this geometry reach 24.5-25.0 dB (profiles/r03 ... r05 full_run_*.json)")
 
 
 def default_args(upsample, epochs=3000):

@@ -22,6 +22,8 @@
 // epilogue (bias, BatchNorm {sum, sum^2} partials, gradient fan-in) are those of the fp32 kernel.
 #include "common.h"
 
+#include <climits>
+#include <iterator>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -1001,12 +1003,15 @@ extern "C" int dpi_pack_forget(const void* w) {
   // calls it after a patch's optimisation has been synchronised, when the patch's network is replaced).
   std::lock_guard<std::mutex> lock(g_pack_mutex);
   int n = 0;
-  for (auto it = g_pack_slots.begin(); it != g_pack_slots.end();) {
-    if (std::get<1>(it->first) == w) {
-      g_pack_dev[std::get<0>(it->first)].free_slots.emplace(it->second.bytes, it->second.p);
+  // the slot map is ordered by (device, weight pointer, ...): one range per device instead of a scan over every slot (a network has ~70 weight tensors
+  // and the per-patch driver forgets them all: the scan was slots x tensors under the global mutex)
+  for (auto& dv : g_pack_dev) {
+    auto it = g_pack_slots.lower_bound(std::make_tuple(dv.first, w, INT_MIN, INT_MIN, INT_MIN, INT_MIN));
+    while (it != g_pack_slots.end() && std::get<0>(it->first) == dv.first && std::get<1>(it->first) == w) {
+      dv.second.free_slots.emplace(it->second.bytes, it->second.p);
       it = g_pack_slots.erase(it);
       ++n;
-    } else ++it;
+    }
   }
   return n;
 }
@@ -1015,19 +1020,20 @@ extern "C" int dpi_pack_release(void) {
   int cur = 0;
   (void)hipGetDevice(&cur);
   int rc = DPI_OK;
-  for (auto& kv : g_pack_dev) {
-    if (kv.second.chunks.empty()) continue;
-    // every OWNING device is synchronised before its chunks go (a launch on any of its streams may still read a slot)
-    if (hipSetDevice(kv.first) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-      (void)hipGetLastError(); dpi_set_error("dpi_pack_release: synchronising device %d failed", kv.first); rc = DPI_E_LAUNCH; continue;
+  for (auto it = g_pack_dev.begin(); it != g_pack_dev.end();) {
+    const int dev = it->first;
+    // every OWNING device is synchronised before its chunks go (a launch on any of its streams may still read a slot).  A device that cannot be
+    // synchronised keeps its chunks AND its slots (nothing of it is freed: later launches there still find valid memory); every other device's
+    // chunks, slots and free list go together, so no slot ever points into freed memory.
+    if (!it->second.chunks.empty() && (hipSetDevice(dev) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) {
+      (void)hipGetLastError(); dpi_set_error("dpi_pack_release: synchronising device %d failed (its scratch is kept)", dev); rc = DPI_E_LAUNCH; ++it; continue;
     }
-    for (void* p : kv.second.chunks) (void)hipFree(p);
+    for (void* p : it->second.chunks) (void)hipFree(p);
+    for (auto sl = g_pack_slots.begin(); sl != g_pack_slots.end();) sl = std::get<0>(sl->first) == dev ? g_pack_slots.erase(sl) : std::next(sl);
+    it = g_pack_dev.erase(it);
   }
   (void)hipSetDevice(cur);
-  if (rc != DPI_OK) return rc;
-  g_pack_dev.clear();
-  g_pack_slots.clear();
-  return DPI_OK;
+  return rc;
 }
 static size_t bf16_pack_bytes(int kd, int cin, int cout, int ns) { return (size_t)2 * cdiv(cout, 32) * cdiv(cin, 8) * ns * ((kd * 9 + 3) / 4) * 512 * sizeof(unsigned short); }
 

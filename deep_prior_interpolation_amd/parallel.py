@@ -196,10 +196,16 @@ class _Replayer:
         except Exception as exc:      # surfaced by the main thread (close())
             self.error = exc
 
-    def close(self):
+    def close(self, primary=None):
+        """Stop the thread.  A replay error is raised here — chained to `primary` (the exception already in flight in the main thread, if any)
+        instead of replacing it."""
         self.stop = True
         self.thread.join()
+        with self.lock:
+            del self.entries[:]
         if self.error is not None:
+            if primary is not None:
+                raise self.error from primary
             raise self.error
 
 
@@ -268,11 +274,14 @@ def _optimise_rolling(args, patches, origins, acc, Ts, queue, save, device, chec
         T.elapsed = perf_counter() - slot[k]["t0"]
         T._best_for_acc = T._out_best_dev.reshape(T._out_best_dev.shape[2:])
         done(T, slot[k]["i"])
+    primary = None
     try:
         for k in range(len(Ts)):
             if not start(k):
                 break
         while any(s_ is not None for s_ in slot):
+            if rep.error is not None:                        # checked at the TOP of every poll round: no finish() / set-up of a next patch behind a failed replay
+                break
             progressed = False
             for k, s_ in enumerate(slot):
                 if s_ is None:
@@ -288,12 +297,24 @@ def _optimise_rolling(args, patches, origins, acc, Ts, queue, save, device, chec
                     finish(k)
                     start(k)
                     progressed = True
-            if rep.error is not None:
-                break
             if not progressed:
                 sleep(0.001)
+    except BaseException as exc:
+        primary = exc
+        raise
     finally:
-        rep.close()
+        # take every slot out of the replay thread's hands and let its stream drain BEFORE the Interpolators (graphs, private pools) are dropped
+        for s_ in slot:
+            if s_ is not None:
+                rep.remove(s_["entry"])
+        rep.stop = True
+        rep.thread.join()
+        for st in streams:
+            try:
+                st.synchronize()
+            except Exception:                                # noqa: BLE001 — a failed stream must not mask the error that brought us here
+                pass
+        rep.close(primary)
     return mine, t_prep[0]
 
 
