@@ -256,11 +256,11 @@ def test_conv_at_field_scale_patch(ops, cin, cout, k):
 
 
 # ---------------------------------------------------------------- the whole net at the bench geometry against the REFERENCE ----------
-@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_whole_net_first_iterations_at_bench_geometry_against_the_reference_recording(seed):
     """The assembled default MulResUnet3D (5 923 614 parameters) on the 256x128x128 patch — the geometry the metric is quoted on — against the
     REFERENCE's own recording of iterations 0..2 there (tests/golden/snr_bench_head_256x128x128.npz, oracle/make_snr_spread.py --mid 256 128 128:
-    the reference's Interpolator on CPU; loss[0] = 1.3799078 / 1.3789475 / 1.3842244 for seeds 0 / 1 / 2).
+    the reference's Interpolator on CPU; loss[0] = 1.3799078 / 1.3789475 / 1.3842244 / 1.3787661 / 1.3768623 / 1.3775539 for seeds 0 .. 5; seeds 3-5 recorded in round 6).
     --noise_source torch_cpu reproduces the reference's stream (u.set_seed(s) -> build_model -> z = 0.1 * N(0,1) -> 0.03 * z.clone().normal_() per
     iteration from torch's CPU generator, order of reference main.py:59-64,148-150; the CPU half of that is pinned without a GPU by
     tests/test_host.py::test_torch_cpu_noise_source_reproduces_the_reference_stream), so iteration 0 is THE SAME function of THE SAME numbers on both
