@@ -83,7 +83,7 @@ def _up2_linear_axis(x, axis):
     """x2 linear interpolation, align_corners=False, along one axis:
     out[2i] = .25 x[i-1] + .75 x[i];  out[2i+1] = .75 x[i] + .25 x[i+1]  (edge-clamped)."""
     n = x.shape[axis]
-    idx = torch.arange(n)
+    idx = torch.arange(n, device=x.device)
     lo = x.index_select(axis, torch.clamp(idx - 1, min=0))
     hi = x.index_select(axis, torch.clamp(idx + 1, max=n - 1))
     even = 0.25 * lo + 0.75 * x

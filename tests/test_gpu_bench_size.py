@@ -299,3 +299,105 @@ def test_whole_net_first_iterations_at_bench_geometry_against_the_reference_reco
     assert abs(snr[0] - rs[0]) < 1e-3 and abs(pc[0] - rp[0]) < 1e-4
     assert abs(loss[1] - rl[1]) <= 2e-3 * rl[1]
     assert abs(loss[2] - rl[2]) <= 5e-2 * rl[2]
+
+
+def test_whole_net_gradients_at_bench_geometry_against_float64_and_the_reference_recording():
+    """The whole BACKWARD at the bench geometry, three ways.  (1) The HIP path, fed the reference's own input stream (--noise_source torch_cpu: the weights, z
+    and perturbation of the reference's seed 0), iteration 0, with the schedule of the timed path (side streams, branch stream, fused fan-in).  (2) The
+    TRUTH: the oracle (oracle/dpi_oracle.py) in float64 on the same weights and input, evaluated here on the GPU through torch's generic double-precision ops
+    (test infrastructure; 4.2 M voxels are out of reach of a CPU oracle in test time).  (3) The REFERENCE's own fp32 autograd, recorded on CPU by
+    oracle/make_bench_grads.py with 2 and with 3 threads (tests/golden/bench_grads_256x128x128_seed0*.npz: per parameter tensor the gradient's norm, its dot
+    product with a fixed +-1 vector — a checksum over all of its elements — and its first 64 values).
+    What the three show (round 6, `pytest -s`): fp32 gradients at this size are ill-conditioned in BOTH implementations — the error against float64 grows
+    from 5e-5 (norm-wise) at the output layer to 5e-3 at the first encoder block as the backward pass walks down the net (every conv + BatchNorm stage
+    roughly doubles a relative perturbation, backward as forward), and the reference's own fp32 checksums sit 1e-4 ... 4e-3 from the truth (median 1.2e-3; HIP
+    1.8e-3).  Where HIP and the reference differ by up to 1e-2 of a tensor's norm, neither is "the" gradient.
+    Asserted: every conv-weight gradient of the HIP path within 1.5e-2 (norm-wise) of the float64 truth, every BatchNorm gradient that is not analytically
+    zero within 3e-2, and the HIP checksums in the same error class as the reference's own fp32 gradients: median error at most 2.5 x the reference's
+    (the criterion of the 32^3 test, tests/test_gpu_nets.py::test_full_size_net_one_step_vs_oracle, at the geometry the metric is quoted on)."""
+    import os
+    from deep_prior_interpolation_amd import ops as _ops, utils as u
+    from deep_prior_interpolation_amd.main import Interpolator
+    from deep_prior_interpolation_amd.optim import FusedAdam
+    from deep_prior_interpolation_amd.parameter import parse_arguments
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(gold, "snr_bench_head_256x128x128.npz"))
+    g2 = np.load(os.path.join(gold, "bench_grads_256x128x128_seed0.npz"))                # reference, 2 CPU threads
+    g3 = np.load(os.path.join(gold, "bench_grads_256x128x128_seed0_threads3.npz"))       # reference, 3 CPU threads
+    if str(g2["torch"]) != torch.__version__:
+        pytest.skip("the CPU generator's stream is pinned to torch %s" % g2["torch"])
+    seed = int(g2["seed"])
+    vol = u.hyperbolic_volume(FULL, seed=0)
+    mask = u.random_trace_mask(FULL, 0.66, seed=1)
+    args = parse_arguments(str(z["argv"]).split() + ["--epochs", "3", "--gpu", "0", "--noise_source", "torch_cpu"])
+    args.param_noise = False
+    u.set_seed(seed)
+    T = Interpolator(args, "/tmp", seed=seed)
+    T.load_data({"image": (vol.astype(np.float64) * args.gain)[..., None], "mask": mask.astype(np.float64)[..., None], "name": "0"})
+    T.build_model()
+    T.build_input()
+    init = {k: v.detach().clone() for k, v in T.net.state_dict().items()}                # on the GPU
+    inp = T.perturbed_input()                                                             # the reference's iteration-0 input, bit for bit
+    T.optimizer = FusedAdam(T.net.parameters(), lr=args.lr)
+    _ops.set_weight_grad_overlap(True)
+    try:
+        T.optimizer.zero_grad()
+        T.optimization_loop(inp)
+    finally:
+        _ops.set_weight_grad_overlap(False)
+    torch.cuda.synchronize()
+    assert abs(T.history.loss[0] - float(g2["loss0"])) <= 1e-5 * float(g2["loss0"])
+    names = [str(n) for n in g2["names"]]
+    params = list(T.net.named_parameters())
+    assert [n for n, _ in params] == names
+    hip = {n: (None if p.grad is None else p.grad.detach().double()) for n, p in params}
+    img64, mask64 = T.img_.double(), T.mask_.double()
+    T.optimizer = None
+    T.net.zero_grad(set_to_none=True)
+    torch.cuda.empty_cache()
+    # ---- the truth: float64 oracle on the GPU
+    S = O.NetState(init, dtype=torch.float64)
+    S.track_running = False
+    out64 = O.net_forward(S, inp.double(), {"ndim": 3, "filters": args.filters, "skip": args.skip, "upsample": "trilinear"})
+    loss64 = O.masked_loss(out64, img64, mask64, "mae")
+    loss64.backward()
+    assert abs(T.history.loss[0] - loss64.item()) <= 1e-6 * loss64.item()
+    del out64
+    rows, n_conv = [], 0
+    worst = {"conv vs float64": 0.0, "BatchNorm vs float64": 0.0}
+    n_bn = n_zero = n_none = 0
+    bn_scale = float(np.median(g2["norm"][g2["ndim"] == 1]))
+    for k, (n, p) in enumerate(params):
+        t = S.P[n].grad.flatten()
+        tn = float(t.norm())
+        if hip[n] is None:                                    # a conv bias in front of a BatchNorm: analytically zero (the truth says so)
+            n_none += 1
+            assert p.ndim == 1 and tn < 1e-9, (n, tn)
+            continue
+        gh = hip[n].flatten()
+        assert gh.numel() == int(g2["numel"][k]) and bool(torch.isfinite(gh).all()), n
+        if p.ndim > 1 or tn > 1e-4 * bn_scale:
+            sign = torch.from_numpy(np.random.RandomState(1234 + k).randint(0, 2, size=gh.numel()).astype(np.float64) * 2.0 - 1.0).to(gh.device)
+            e_hip = float((gh - t).norm()) / tn
+            dot64 = float(torch.dot(t, sign))
+            c_hip = abs(float(torch.dot(gh, sign)) - dot64) / tn
+            c_ref = max(abs(float(g2["dot"][k]) - dot64), abs(float(g3["dot"][k]) - dot64)) / tn
+            if p.ndim > 1:
+                n_conv += 1
+                worst["conv vs float64"] = max(worst["conv vs float64"], e_hip)
+                rows.append((abs(float(g2["dot"][k]) - float(torch.dot(gh, sign))) / tn, c_hip, c_ref, e_hip, n, gh.numel()))
+            else:
+                n_bn += 1
+                worst["BatchNorm vs float64"] = max(worst["BatchNorm vs float64"], e_hip)
+        else:
+            n_zero += 1
+            assert float(gh.norm()) < 1e-5 + 100 * max(float(g2["norm"][k]), float(g3["norm"][k])), n
+    print("checksums relative to the tensor norm, worst HIP-vs-reference first:")
+    for row in sorted(rows, key=lambda r: -r[3])[:10]:
+        print("  HIP vs reference %.2e | HIP vs float64 %.2e | reference vs float64 %.2e | HIP vs float64 norm-wise %.2e   %-30s %d values" % row)
+    print("gradients at 256x128x128: %d conv tensors, %d BatchNorm tensors with a real gradient, %d analytically zero, %d None; worst norm-wise errors of the HIP path %s; "
+          "median checksum error HIP %.2e, reference %.2e" % (n_conv, n_bn, n_zero, n_none, {k: "%.2e" % v for k, v in worst.items()},
+                                                              float(np.median([r[1] for r in rows])), float(np.median([r[2] for r in rows]))))
+    assert n_conv == 49 and n_none == 48 and n_bn > 50        # the 49 convolution weight tensors of the net: every layer is in the comparison
+    assert worst["conv vs float64"] < 1.5e-2 and worst["BatchNorm vs float64"] < 3e-2, worst
+    assert float(np.median([r[1] for r in rows])) <= 2.5 * float(np.median([r[2] for r in rows]))
