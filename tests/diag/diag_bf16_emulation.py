@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Diagnostic behind tests/test_gpu_bf16_storage.py::test_whole_net_in_storage_mode_against_the_fp64_oracle_with_the_same_rounding_points:
 block-by-block distance between the HIP net in bf16 storage mode and the fp64 oracle with emulated rounding points (and a few variants of
-the emulation), so that a wrong rounding point shows up at the first block it affects.   python tools/diag_bf16_emulation.py"""
+the emulation), so that a wrong rounding point shows up at the first block it affects.   python tests/diag/diag_bf16_emulation.py"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402

@@ -794,7 +794,7 @@ def test_whole_net_in_storage_mode_against_the_fp64_oracle_with_the_same_roundin
       * a 3x3x3 layer (stride 1 or 2) rounds BOTH matrix operands to bf16 — the chained input T(stored) and the weights; a 1x1x1 layer multiplies the
         stored (bf16) input with fp32 weights on the fp32 MFMA (tools/diag_bf16_weights.py shows each of these on single launches);
       * BatchNorm statistics are those of the stored values; chains, joins, sums, loss: fp32 (the oracle: fp64).
-    What can and cannot be asserted (tools/diag_bf16_emulation.py prints every stage): where fp32 accumulation lands a value on the other side of a bf16
+    What can and cannot be asserted (tests/diag/diag_bf16_emulation.py prints every stage): where fp32 accumulation lands a value on the other side of a bf16
     rounding boundary than fp64 does, ONE element differs by a bf16 ulp, and every conv + BatchNorm stage that follows roughly doubles such a difference
     (2.5e-5 after the first layer, 1e-4 after the first block, 1e-2 at the output ten stages later) — the net is as chaotic forward as the loop is over
     iterations.  So the rounding points are pinned where they are first used, against the WRONG alternatives: at the first block the emulation must be

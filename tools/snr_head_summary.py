@@ -20,12 +20,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bf16", action="store_true", help="the six bf16-storage seeds of profiles/r05/snr_head_hip6_bf16.json instead")
     ap.add_argument("--r05-only", action="store_true", help="only the twelve default-path seeds of round 5")
+    ap.add_argument("--aten", action="store_true", help="the THIRD implementation instead of the HIP path: the oracle's restatement of the reference loop on aten GPU kernels "
+                                                        "(tests/diag/snr_protocol_aten_gpu.py, profiles/r06/snr_head_aten_gpu*.json)")
     a = ap.parse_args()
     z = np.load(os.path.join(ROOT, "tests", "golden", "snr_bench_head_256x128x128.npz"))
     ref, its = z["snr"].astype(np.float64), np.asarray(z["iterations"]).astype(int)
     files = [os.path.join(ROOT, "profiles", "r05", f) for f in (["snr_head_hip6_bf16.json"] if a.bf16 else ["snr_head_hip6.json", "snr_head_hip6_seeds6to11.json"])]
     if not a.bf16 and not a.r05_only:
-        files += sorted(glob.glob(os.path.join(ROOT, "profiles", "r06", "snr_head_*.json")))
+        files += [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r06", "snr_head_*.json"))) if "aten" not in os.path.basename(f)]
+    if a.aten:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06", "snr_head_aten_gpu*.json")))
     runs = []
     for f in files:
         with open(f) as fp:
@@ -34,7 +38,7 @@ def main():
         print("%-48s %2d runs  (z %s, dead biases %s, noise offset %s)" % (os.path.basename(f), len(d["runs"]), d.get("z", "philox"), d.get("dead_bias", "off"), d.get("noise_offset", 0)))
     n = min(len(r["snr"]) for r in runs)
     mine = np.array([r["snr"][:n] for r in runs])
-    print("reference seeds %s recorded to iteration %s; HIP runs: %d (%s)" % ([int(s) for s in z["seed"]], [int(k) for k in its], len(mine), "bf16 storage" if a.bf16 else "fp32"))
+    print("reference seeds %s recorded to iteration %s; %s runs: %d (%s)" % ([int(s) for s in z["seed"]], [int(k) for k in its], "aten-GPU (third implementation; printed as HIP below)" if a.aten else "HIP", len(mine), "bf16 storage" if a.bf16 else "fp32"))
     for it in (100, 150, 220, 250, 300, 350, 400, 450, 500, 550, 599):
         cover = [k for k in range(ref.shape[0]) if its[k] > it]
         if len(cover) < 2 or it >= n:
