@@ -428,7 +428,7 @@ def finish_backward(params=None):
 # Only inside an Interpolator iteration with the weight-gradient overlap on (patches >= 2^20 voxels, eager loop).
 # ------------------------------------------------------------------------------------------------
 BRANCH_STREAMS = os.environ.get("DPI_BRANCH", "1") == "1"
-BRANCH_SHORTCUT = int(os.environ.get("DPI_BRANCH_SHORT", "0"))   # 2 (round 6): beside the SECOND and THIRD 3x3x3 layer of the block instead (4->8, 8->13: matrix-bound, they read 4 / 8 channels), started once the first one has drained; 1:     # OFF: the first 3x3x3 layer of a block (64->4, 67->4, 25->8: few output channels) is itself at ~half the HBM bandwidth, the 1x1x1 layer beside it gains nothing (64->4 0.70 -> 1.05 ms with the 0.35 ms shortcut beside it; 31.1-31.5 ms per iteration with, 30.6-30.8 without)
+BRANCH_SHORTCUT = int(os.environ.get("DPI_BRANCH_SHORT", "0"))   # 0: OFF.  2 (round 6): beside the SECOND and THIRD 3x3x3 layer of the block (4->8, 8->13: matrix-bound, they read 4 / 8 channels), started once the first one has drained — measured +0.3 ms (29.7-30.1 against 29.3-29.5, profiles/r06/ab_fanin_shortcut.txt).  1: beside the first layer:     # OFF: the first 3x3x3 layer of a block (64->4, 67->4, 25->8: few output channels) is itself at ~half the HBM bandwidth, the 1x1x1 layer beside it gains nothing (64->4 0.70 -> 1.05 ms with the 0.35 ms shortcut beside it; 31.1-31.5 ms per iteration with, 30.6-30.8 without)
 BRANCH_SKIP = os.environ.get("DPI_BRANCH_SKIP", "1") == "1"
 BRANCH_SKIP_BWD = os.environ.get("DPI_BRANCH_SKIP_BWD", "1") == "1"
 _branch_streams = {}
