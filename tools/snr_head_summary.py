@@ -38,7 +38,7 @@ def main():
         print("%-48s %2d runs  (z %s, dead biases %s, noise offset %s)" % (os.path.basename(f), len(d["runs"]), d.get("z", "philox"), d.get("dead_bias", "off"), d.get("noise_offset", 0)))
     n = min(len(r["snr"]) for r in runs)
     mine = np.array([r["snr"][:n] for r in runs])
-    print("reference seeds %s recorded to iteration %s; %s runs: %d (%s)" % ([int(s) for s in z["seed"]], [int(k) for k in its], "aten-GPU (third implementation; printed as HIP below)" if a.aten else "HIP", len(mine), "bf16 storage" if a.bf16 else "fp32"))
+    print("reference seeds %s recorded to iteration %s; %s runs: %d (%s)" % ([int(s) for s in z["seed"]], [int(k) for k in its], "aten-GPU (third implementation; printed as HIP below)" if a.aten else "HIP", len(mine), "bf16 storage" if a.bf16 else d.get("precision", "fp32")))
     for it in (100, 150, 220, 250, 300, 350, 400, 450, 500, 550, 599):
         cover = [k for k in range(ref.shape[0]) if its[k] > it]
         if len(cover) < 2 or it >= n:
