@@ -277,22 +277,22 @@ def test_head_of_the_run_at_bench_geometry_is_not_behind_the_reference():
 # documented and open — with reference seeds 0-2 alone the lead at iteration 599 is +1.2 dB against a bar of 1.1; seeds 3-5, recorded through
 # round 6, sit inside the HIP distribution (13.1 / 13.2 / 13.4 dB at iteration 150 against HIP 13.2 +- 0.8; 15.3 / 15.8 at 220 against 15.6 +- 0.6) and pull
 # every checkpoint they reach inside the bar.  Within the bar the test simply passes.
-HEAD_PARITY_XFAIL = ("open difference at the bench geometry (DESIGN.md §4): the HIP path LEADS the reference's recorded seeds beyond max(3 s.e., 1 dB); "
-                     "not a deficit, no cause found, the later reference seeds close the gap")
+HEAD_PARITY_XFAIL = ("known difference at the bench geometry (DESIGN.md §4): the HIP path LEADS the reference's CPU recordings beyond max(3 s.e., 1 dB) — as does a float64 "
+                     "implementation of the reference's algorithm, which the HIP path tracks within 0.4 dB; not a deficit, not a property of the HIP path")
 
 
 def test_head_of_the_run_at_bench_geometry_matches_the_reference_both_ways():
     """The SYMMETRIC bar (VERDICT / ADVICE round 5: a lead is a difference too): |difference of the means| <= max(3 s.e., 1 dB) at every checkpoint
     from iteration 220 on, s.e. from the sample standard deviations of the six HIP runs and of the reference seeds covering the checkpoint.
-    What is known (`python tools/snr_head_summary.py`): with reference seeds 0..2 the HIP path LEADS by 0.5-1.3 dB through the first 600
-    iterations (12 HIP seeds: +1.30 dB = 3.8 s.e. at iteration 599; +1.1 / +0.8 / +0.5 / +0.8 at 220 / 300 / 400 / 500).  Round 6 looked for a cause
-    and excluded, one by one (27 further HIP runs, profiles/r06/): the network itself — iteration 0 of the assembled net at this size equals the
-    reference's recorded loss to 5e-8 with the reference's own z and perturbation, iteration 1 to 1e-3 (tests/test_gpu_bench_size.py) —, the ~3.3 k
-    dead conv biases the reference Adam-steps on rounding residues (`--dead-bias sum` / `noise`: same curve, +1.4 dB at 599), z from another
-    generator and the reference's OWN z and initial weights per seed (`--z torch_cpu`: +0.9 ... +1.3), the per-iteration noise generator and the
-    stream schedule (round 5), fp32 accuracy of the CPU's weight gradients at this size (3.7e-5 norm-wise).  Paired runs show that the spread is
-    chaotic, not seed-borne (0.5 dB between runs that share weights and z, 0.3 dB between seeds), so every reference run is one draw of ~0.5 dB:
-    seed 0 sits 2-3 such deviations low throughout, seeds 1 and 2 about one."""
+    What is known (`python tools/snr_head_table.py`): with reference seeds 0..2 the HIP path LEADS by 0.5-1.3 dB through the first 600 iterations
+    (51 HIP runs: +1.14 dB at iteration 599).  Round 6 (a) excluded every cause it could name — the network itself (iteration 0 of the assembled net at this size
+    equals the reference's recorded loss to 5e-8 with the reference's own z and perturbation, tests/test_gpu_bench_size.py), the ~3.3 k dead conv biases the
+    reference Adam-steps on rounding residues, z (incl. the reference's OWN z and weights per seed), generators, schedule, Adam, gradient accuracy —, (b) recorded
+    reference seeds 3..5, which sit inside the HIP distribution where they got, and (c) ran the reference's ALGORITHM in float64 on aten GPU kernels, six seeds:
+    the HIP path tracks that implementation within 0.4 dB (<= 1.2 s.e.) at every checkpoint and both sit above the CPU recordings.  So an excess over the bar here
+    is a statement about the reference's CPU recordings at this size, not about the HIP path; it is reported as an expected failure (HEAD_PARITY_XFAIL) so
+    that `pytest -x` goes on, and printed.  Paired runs show that the spread is chaotic, not seed-borne (0.5 dB between runs that share weights and z, 0.3 dB
+    between seeds): every run is one draw of ~0.5 dB; seed 0 of the reference sits 2-3 such deviations low throughout."""
     c = _head_comparison()
     over = [r for r in c["rows"] if r["it"] >= 220 and abs(r["diff"]) > r["bar"]]
     if over and HEAD_PARITY_XFAIL:
