@@ -104,9 +104,9 @@ SNR_STATEMENT = ("HIP vs the reference's own Interpolator, same volume / mask / 
                  "and every gradient of iteration 0 is within 6e-3 of a float64 evaluation (tests/test_gpu_bench_size.py).  Over the heads of the runs (600 iterations; a "
                  "reference iteration costs a minute of CPU) THREE implementations were compared (DESIGN.md §4; python tools/snr_head_table.py): 51 HIP runs reach 15.6 / 16.9 / 18.0 / "
                  "18.8 / 19.4 dB at iterations 220 / 300 / 400 / 500 / 599; the reference's ALGORITHM in float64 on aten GPU kernels (6 seeds) 15.6 / 16.8 / 17.7 / 18.4 / 19.2 — "
-                 "the HIP path tracks it within 0.4 dB (<= 1.2 s.e.) everywhere; the reference's CPU fp32 runs (six seeds: 0-2 from rounds 4-5, 3-5 recorded through round 6; five reach "
-                 "iteration 599) 15.1 / 16.3 / 17.7 / 18.2 / 18.6 — the HIP runs lead them by +0.4 / +0.6 / +0.3 / +0.6 / +0.8 dB (1.0 / 2.4 / 1.5 / 2.0 / 2.1 s.e.; against seeds 0-2 alone "
-                 "it was +1.1 dB at 599: the later seeds sit inside the HIP distribution and halve the lead), the float64 runs by 0.0-0.6 dB.  So: not a deficit and not a property of "
+                 "the HIP path tracks it within 0.4 dB (<= 1.2 s.e.) everywhere; the reference's CPU fp32 runs (six seeds to iteration 600: 0-2 from rounds 4-5, 3-5 recorded through round 6) "
+                 "15.1 / 16.3 / 17.7 / 18.2 / 18.8 — the HIP runs lead them by +0.4 / +0.6 / +0.3 / +0.6 / +0.6 dB (1.0 / 2.4 / 1.5 / 2.0 / 1.7 s.e.; against seeds 0-2 alone "
+                 "it was +1.1 dB at 599: the later seeds sit inside the HIP distribution and halve the lead), the float64 runs by 0.0-0.5 dB.  So: not a deficit and not a property of "
                  "the HIP path; the remaining half dB is at the edge of what six reference draws resolve — whether the draw or torch's CPU fp32 kernels at 4.2 M "
                  "voxels is behind it is not decided (excluded: the net itself, dead conv biases, z, paired seeds, generators, schedule, Adam, gradient accuracy).  One level "
                  "below (128x64x64, 1200 iterations, the smallest volume that runs this patch's kernel variants): SNR(out_best) +0.00 dB +- 0.35 (2 s.e., n = 12 + 9; bf16 "
